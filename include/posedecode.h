@@ -1,0 +1,166 @@
+/*
+ * libposedecode -- C ABI of the MI355X (gfx950) OpenPose decode path.
+ *
+ * The reference has no FFI layer: its boundary is plain Python functions
+ * (utils/postprocess.py:26,78,163 and the decode half of predict.py:45-254).
+ * Each entry point below names the reference interface it stands in for.  All
+ * entry points return an int status (0 = PD_OK, < 0 = error, text via
+ * pd_last_error).  Pointers are plain host or device addresses as stated by the
+ * `mem` argument; no framework types cross this boundary.
+ *
+ * Threading: one context per GPU stream; a context is not re-entrant, distinct
+ * contexts are independent.  The library owns all device memory inside a
+ * context; the caller owns every buffer it passes in.  Variable-length outputs
+ * are returned packed, with their sizes reported first (pd_sync_totals), and an
+ * image that exceeds a capacity given at pd_create makes the call fail with
+ * PD_E_OVERFLOW -- results are never truncated silently.
+ */
+#ifndef POSEDECODE_H
+#define POSEDECODE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD_N_PARTS 18 /* cfg.ch_heats - 1, cfgs/config_vgg19.py:76 */
+#define PD_N_LIMBS 19 /* len(cfg.map_idx), cfgs/config_vgg19.py:59-63 */
+#define PD_CH_HEAT 19
+#define PD_CH_PAF 38
+
+enum {
+    PD_OK = 0,
+    PD_E_INVALID = -1,  /* bad argument / shape (Python: ValueError) */
+    PD_E_HIP = -2,      /* HIP runtime error */
+    PD_E_OVERFLOW = -3, /* a capacity from pd_config was exceeded */
+    PD_E_INDEX = -4,    /* mode D: a connection touches > 2 persons; predict.py:195-200 raises IndexError */
+    PD_E_STATE = -5     /* stage called before the stage that feeds it */
+};
+
+enum { PD_MODE_P = 0, /* utils/postprocess.py semantics */
+       PD_MODE_D = 1  /* predict.py detect() semantics */ };
+enum { PD_MEM_HOST = 0, PD_MEM_DEVICE = 1 };
+enum { PD_F32 = 0, PD_F64 = 1 };
+enum { PD_IMPL_FAST = 0,  /* streaming fused kernels */
+       PD_IMPL_SIMPLE = 1 /* one-thread-per-pixel kernels, any image size; used as an on-GPU cross-check */ };
+
+typedef struct pd_ctx pd_ctx;
+
+typedef struct {
+    int32_t device_id;
+    int32_t max_batch;           /* images per call */
+    int32_t max_h, max_w;        /* full-resolution image size */
+    int32_t max_peaks_per_part;  /* per image and body part */
+    int32_t max_persons;         /* per image, before pruning */
+    int32_t max_pairs_per_image; /* sum over limbs of nA*nB */
+    int32_t fullres;             /* != 0: allocate the full-resolution planes needed by
+                                    pd_upsample_avg / pd_load_fullres */
+} pd_config;
+
+typedef struct {
+    int32_t y, x;  /* pixel coordinates */
+    double score;  /* unsmoothed heatmap value at (y, x) */
+} pd_peak;
+
+typedef struct {
+    int32_t id_a, id_b; /* global peak ids */
+    int32_t ia, ib;     /* index within the part's peak list */
+    double score;       /* PAF line integral + distance prior */
+} pd_conn;
+
+typedef struct {
+    int32_t n_images;
+    int32_t first_bad_image; /* -1, or the first image whose status is not PD_OK */
+    int64_t n_peaks, n_conns, n_persons;
+} pd_totals;
+
+int pd_create(const pd_config* cfg, pd_ctx** out);
+int pd_destroy(pd_ctx* ctx);
+const char* pd_last_error(pd_ctx* ctx);
+const char* pd_version(void);
+
+/* Which of the two decode variants of the reference to follow (see the enum). */
+int pd_set_mode(pd_ctx* ctx, int mode);
+int pd_set_impl(pd_ctx* ctx, int impl);
+/* The HIP stream the context launches on (a hipStream_t), for callers that time
+ * launches with events or order their own work against it. */
+void* pd_stream(pd_ctx* ctx);
+
+/* ---- stage 1: predict.py:51-72 (multi-scale upsample, un-pad, resize, average) ----
+ * heat[m] is (B, hs[m], ws[m], 19) float32, paf[m] is (B, hs[m], ws[m], 38):
+ * the network outputs of scale m.  Each is resized x8 with the bicubic kernel
+ * (predict.py:63,67), cropped to crop_h[m] x crop_w[m] (:64,:68), resized to
+ * H x W (:65,:69), divided by n_scales in float32 and accumulated in float64
+ * (:71-72).  The averages stay in the context as the source of pd_peaks /
+ * pd_connections; pd_read_fullres copies them out as (B, H, W, C) float64. */
+int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* heat, const float* const* paf,
+                    const int32_t* hs, const int32_t* ws, const int32_t* crop_h,
+                    const int32_t* crop_w, int H, int W, int B, int mem);
+int pd_read_fullres(pd_ctx* ctx, double* heat_out, double* paf_out);
+
+/* Full-resolution maps supplied by the caller, as the arguments of
+ * get_peaks(heatmap, ..) / get_connections(.., pafs, ..) in utils/postprocess.py:
+ * (B, H, W, C) arrays of float32 or float64.  Either pointer may be NULL to keep
+ * what the context already holds.  A float32 heatmap is smoothed with float32
+ * storage after each axis and thresholded in float32, as scipy/numpy do. */
+int pd_load_fullres(pd_ctx* ctx, const void* heat, int heat_dtype, int heat_channels,
+                    const void* paf, int paf_dtype, int paf_channels, int B, int H, int W, int mem);
+
+/* Network-resolution source for the fused path: (B, h, w, 19) and (B, h, w, 38)
+ * float32; the full-resolution map is the x8 bicubic upsample cropped to H x W
+ * (8(h-1) < H <= 8h), evaluated on the fly and never written to memory. */
+int pd_set_lowres(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H,
+                  int W, int mem);
+
+/* ---- stage 2+3: get_peaks, utils/postprocess.py:26-75 (predict.py:88-111) ---- */
+int pd_peaks(pd_ctx* ctx, double thre1);
+/* Peaks supplied by the caller (one image): counts[18], then y/x/score/id arrays
+ * concatenated part by part -- the `peaks` argument of get_connections. */
+int pd_set_peaks(pd_ctx* ctx, const int32_t* counts, const int32_t* y, const int32_t* x,
+                 const double* score, const int32_t* id);
+
+/* ---- stage 4+5: get_connections, utils/postprocess.py:78-160 (predict.py:120-174) ---- */
+int pd_connections(pd_ctx* ctx, double thre2);
+/* Connections supplied by the caller (one image): counts[19] (-1 = limb listed in
+ * special_limb_idx), rows of 5 doubles [id_a, id_b, score, conf_a, conf_b]. */
+int pd_set_connections(pd_ctx* ctx, const int32_t* counts, const double* rows);
+
+/* ---- stage 6: multi_person_parse, utils/postprocess.py:163-237 (predict.py:179-252) ---- */
+int pd_parse(pd_ctx* ctx);
+
+/* ---- the whole decode for a batch: predict.py:82-254 on B images ----
+ * Enqueues set_lowres + peaks + connections + parse + packing on the context's
+ * stream and returns without waiting. */
+int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H,
+                    int W, double thre1, double thre2, int mem);
+/* The same from the full-resolution maps the context holds (after
+ * pd_upsample_avg or pd_load_fullres). */
+int pd_decode_fullres(pd_ctx* ctx, double thre1, double thre2);
+
+/* ---- results ----
+ * pd_pack gathers whatever stages have run into the packed result buffer;
+ * pd_sync_totals waits for the stream and reports sizes (and PD_E_OVERFLOW /
+ * PD_E_INDEX if an image failed); pd_fetch copies the packed results to host
+ * arrays sized from those totals:
+ *   part_count   [B][18]  peaks per part
+ *   limb_count   [B][19]  connections per limb, -1 where nA*nB == 0 ("special")
+ *   person_count [B]
+ *   status       [B]
+ *   peaks        n_peaks entries, image-major, then part-major, then (y, x) ascending
+ *   conns        n_conns entries, image-major, then limb-major, in greedy pick order
+ *   persons      n_persons x 20 doubles, image-major, in row order
+ * Any output pointer may be NULL. */
+int pd_pack(pd_ctx* ctx);
+int pd_sync_totals(pd_ctx* ctx, pd_totals* totals);
+int pd_fetch(pd_ctx* ctx, int32_t* part_count, int32_t* limb_count, int32_t* person_count,
+             int32_t* status, pd_peak* peaks, pd_conn* conns, double* persons);
+
+/* The smoothed heatmap the peak stage compares (scipy.ndimage.gaussian_filter,
+ * sigma = 3), (B, 18, H, W) float64; test hook for the filter alone. */
+int pd_debug_smoothed(pd_ctx* ctx, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEDECODE_H */

@@ -1,0 +1,242 @@
+"""ctypes binding of libposedecode.so (the C ABI declared in include/posedecode.h).
+
+There is no CPU fallback: if the library is missing or no GPU is visible the
+decode raises.  ctypes releases the GIL for the duration of every call.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libposedecode.so')
+
+PD_OK, PD_E_INVALID, PD_E_HIP, PD_E_OVERFLOW, PD_E_INDEX, PD_E_STATE = 0, -1, -2, -3, -4, -5
+MODE_P, MODE_D = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+F32, F64 = 0, 1
+IMPL_FAST, IMPL_SIMPLE = 0, 1
+
+EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mode', 'pd_set_impl',
+           'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
+           'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
+           'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
+           'pd_debug_smoothed']
+
+
+class Config(C.Structure):
+    _fields_ = [('device_id', C.c_int32), ('max_batch', C.c_int32), ('max_h', C.c_int32),
+                ('max_w', C.c_int32), ('max_peaks_per_part', C.c_int32), ('max_persons', C.c_int32),
+                ('max_pairs_per_image', C.c_int32), ('fullres', C.c_int32)]
+
+
+class Totals(C.Structure):
+    _fields_ = [('n_images', C.c_int32), ('first_bad_image', C.c_int32), ('n_peaks', C.c_int64),
+                ('n_conns', C.c_int64), ('n_persons', C.c_int64)]
+
+
+PEAK_DTYPE = np.dtype([('y', np.int32), ('x', np.int32), ('score', np.float64)])
+CONN_DTYPE = np.dtype([('id_a', np.int32), ('id_b', np.int32), ('ia', np.int32), ('ib', np.int32),
+                       ('score', np.float64)])
+
+
+class DecodeOverflow(RuntimeError):
+    """A capacity given at context creation was exceeded (PD_E_OVERFLOW)."""
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libposedecode.so is not built (%s); run `python -c "import __graft_entry__ as g; '
+                           'g.build()"` or `make -C poseestimation_amd/csrc`' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+    L.pd_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.pd_destroy.argtypes = [vp]
+    L.pd_last_error.argtypes = [vp]
+    L.pd_last_error.restype = C.c_char_p
+    L.pd_version.restype = C.c_char_p
+    L.pd_set_mode.argtypes = [vp, i32]
+    L.pd_set_impl.argtypes = [vp, i32]
+    L.pd_stream.argtypes = [vp]
+    L.pd_stream.restype = vp
+    L.pd_upsample_avg.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  i32, i32, i32, i32]
+    L.pd_read_fullres.argtypes = [vp, vp, vp]
+    L.pd_load_fullres.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32]
+    L.pd_set_lowres.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32]
+    L.pd_peaks.argtypes = [vp, dbl]
+    L.pd_set_peaks.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.pd_connections.argtypes = [vp, dbl]
+    L.pd_set_connections.argtypes = [vp, vp, vp]
+    L.pd_parse.argtypes = [vp]
+    L.pd_decode_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, dbl, dbl, i32]
+    L.pd_decode_fullres.argtypes = [vp, dbl, dbl]
+    L.pd_pack.argtypes = [vp]
+    L.pd_sync_totals.argtypes = [vp, C.POINTER(Totals)]
+    L.pd_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pd_debug_smoothed.argtypes = [vp, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ('pd_last_error', 'pd_version', 'pd_stream'):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """Owns one pd_ctx (one GPU, one HIP stream)."""
+
+    def __init__(self, device_id=0, max_batch=1, max_h=368, max_w=368, max_peaks_per_part=128,
+                 max_persons=128, max_pairs_per_image=32768, fullres=False):
+        self._h = None
+        L = lib()
+        cfg = Config(device_id, max_batch, max_h, max_w, max_peaks_per_part, max_persons,
+                     max_pairs_per_image, 1 if fullres else 0)
+        h = C.c_void_p()
+        rc = L.pd_create(C.byref(cfg), C.byref(h))
+        if rc != PD_OK:
+            raise RuntimeError('pd_create failed (%d): %s' % (rc, L.pd_last_error(None).decode()))
+        self._h = h
+        self.cfg = cfg
+        self.L = L
+
+    def close(self):
+        if self._h is not None:
+            self.L.pd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- error mapping: ValueError for bad shapes, IndexError for the mode-D case --
+    def check(self, rc):
+        if rc == PD_OK:
+            return
+        msg = self.L.pd_last_error(self._h).decode()
+        if rc == PD_E_INVALID:
+            raise ValueError(msg)
+        if rc == PD_E_INDEX:
+            raise IndexError(msg)
+        if rc == PD_E_OVERFLOW:
+            raise DecodeOverflow(msg)
+        raise RuntimeError('libposedecode error %d: %s' % (rc, msg))
+
+    @property
+    def stream(self):
+        return self.L.pd_stream(self._h)
+
+    def set_mode(self, mode):
+        self.check(self.L.pd_set_mode(self._h, mode))
+
+    def set_impl(self, impl):
+        self.check(self.L.pd_set_impl(self._h, impl))
+
+    def set_lowres(self, heat, paf, B, h, w, H, W, mem=MEM_HOST):
+        self.check(self.L.pd_set_lowres(self._h, heat, paf, B, h, w, H, W, mem))
+
+    def load_fullres(self, heat, paf, B, H, W):
+        """heat / paf: C-contiguous (B, H, W, C) float32 or float64 numpy arrays or None."""
+        def desc(a):
+            if a is None:
+                return None, F64, 0
+            return C.c_void_p(a.ctypes.data), (F32 if a.dtype == np.float32 else F64), a.shape[-1]
+        hp, hd, hc = desc(heat)
+        pp, pdt, pc = desc(paf)
+        self.check(self.L.pd_load_fullres(self._h, hp, hd, hc, pp, pdt, pc, B, H, W, MEM_HOST))
+
+    def upsample_avg(self, heat_list, paf_list, crops, H, W, B):
+        n = len(heat_list)
+        hp = (C.c_void_p * n)(*[a.ctypes.data for a in heat_list])
+        pp = (C.c_void_p * n)(*[a.ctypes.data for a in paf_list])
+        hs = (C.c_int32 * n)(*[a.shape[1] for a in heat_list])
+        ws = (C.c_int32 * n)(*[a.shape[2] for a in heat_list])
+        ch = (C.c_int32 * n)(*[c[0] for c in crops])
+        cw = (C.c_int32 * n)(*[c[1] for c in crops])
+        self.check(self.L.pd_upsample_avg(self._h, n, hp, pp, hs, ws, ch, cw, H, W, B, MEM_HOST))
+
+    def read_fullres(self, B, H, W, want_heat=True, want_paf=True):
+        heat = np.empty((B, H, W, 19), np.float64) if want_heat else None
+        paf = np.empty((B, H, W, 38), np.float64) if want_paf else None
+        self.check(self.L.pd_read_fullres(self._h, _ptr(heat), _ptr(paf)))
+        return heat, paf
+
+    def peaks(self, thre1):
+        self.check(self.L.pd_peaks(self._h, float(thre1)))
+
+    def set_peaks(self, counts, y, x, score, ids):
+        counts = np.ascontiguousarray(counts, np.int32)
+        y = np.ascontiguousarray(y, np.int32)
+        x = np.ascontiguousarray(x, np.int32)
+        score = np.ascontiguousarray(score, np.float64)
+        ids = np.ascontiguousarray(ids, np.int32)
+        self.check(self.L.pd_set_peaks(self._h, _ptr(counts), _ptr(y), _ptr(x), _ptr(score), _ptr(ids)))
+
+    def connections(self, thre2):
+        self.check(self.L.pd_connections(self._h, float(thre2)))
+
+    def set_connections(self, counts, rows):
+        counts = np.ascontiguousarray(counts, np.int32)
+        rows = np.ascontiguousarray(rows, np.float64)
+        self.check(self.L.pd_set_connections(self._h, _ptr(counts), _ptr(rows)))
+
+    def parse(self):
+        self.check(self.L.pd_parse(self._h))
+
+    def decode_batch(self, heat, paf, B, h, w, H, W, thre1, thre2, mem=MEM_HOST):
+        self.check(self.L.pd_decode_batch(self._h, heat, paf, B, h, w, H, W, float(thre1), float(thre2), mem))
+
+    def decode_fullres(self, thre1, thre2):
+        self.check(self.L.pd_decode_fullres(self._h, float(thre1), float(thre2)))
+
+    def pack(self):
+        self.check(self.L.pd_pack(self._h))
+
+    def sync_totals(self):
+        t = Totals()
+        self.check(self.L.pd_sync_totals(self._h, C.byref(t)))
+        return t
+
+    def fetch(self):
+        """Packed results of the stages that ran, as numpy arrays."""
+        t = self.sync_totals()
+        B = t.n_images
+        out = {
+            'B': B,
+            'part_count': np.zeros((B, 18), np.int32),
+            'limb_count': np.zeros((B, 19), np.int32),
+            'person_count': np.zeros((B,), np.int32),
+            'status': np.zeros((B,), np.int32),
+            'peaks': np.zeros((t.n_peaks,), PEAK_DTYPE),
+            'conns': np.zeros((t.n_conns,), CONN_DTYPE),
+            'persons': np.zeros((t.n_persons, 20), np.float64),
+        }
+        self.check(self.L.pd_fetch(self._h, _ptr(out['part_count']), _ptr(out['limb_count']),
+                                   _ptr(out['person_count']), _ptr(out['status']), _ptr(out['peaks']),
+                                   _ptr(out['conns']), _ptr(out['persons'])))
+        return out
+
+    def debug_smoothed(self, B, H, W):
+        out = np.empty((B, 18, H, W), np.float64)
+        self.check(self.L.pd_debug_smoothed(self._h, _ptr(out)))
+        return out

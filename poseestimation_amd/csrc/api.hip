@@ -1,0 +1,581 @@
+// C ABI of libposedecode: context management, sources, stage entry points, results.
+#include <stdlib.h>
+
+#include <new>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+static thread_local char g_err[256] = "";
+
+#define PD_CHECK_CTX(ctx) \
+    if ((ctx) == nullptr) return PD_E_INVALID;
+
+static int dev_alloc(pd_ctx* ctx, void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    PD_HIP(ctx, hipMalloc(p, bytes));
+    return PD_OK;
+}
+
+static int ensure(pd_ctx* ctx, void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return PD_OK;
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*p) PD_HIP(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    PD_HIP(ctx, hipMalloc(p, bytes));
+    *cap = bytes;
+    return PD_OK;
+}
+
+extern "C" const char* pd_version(void) { return "posedecode 0.1 (gfx950)"; }
+
+extern "C" const char* pd_last_error(pd_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
+    if (!cfg || !out) return PD_E_INVALID;
+    *out = nullptr;
+    if (cfg->max_batch < 1 || cfg->max_h < 1 || cfg->max_w < 1 || cfg->max_peaks_per_part < 1 ||
+        cfg->max_persons < 1 || cfg->max_pairs_per_image < 1) {
+        snprintf(g_err, sizeof(g_err), "pd_create: capacities must be positive");
+        return PD_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        snprintf(g_err, sizeof(g_err), "pd_create: no HIP device visible");
+        return PD_E_HIP;
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) {
+        snprintf(g_err, sizeof(g_err), "pd_create: device %d of %d", cfg->device_id, ndev);
+        return PD_E_INVALID;
+    }
+    pd_ctx* ctx = new (std::nothrow) pd_ctx;
+    if (!ctx) return PD_E_HIP;
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->cfg = *cfg;
+    ctx->mode = PD_MODE_P;
+    ctx->impl = PD_IMPL_FAST;
+#define CR(call)                                                                     \
+    do {                                                                             \
+        int rc_ = (call);                                                            \
+        if (rc_ != PD_OK) {                                                          \
+            snprintf(g_err, sizeof(g_err), "%s", ctx->err);                          \
+            pd_destroy(ctx);                                                         \
+            return rc_;                                                              \
+        }                                                                            \
+    } while (0)
+#define CRH(call)                                                                    \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            snprintf(g_err, sizeof(g_err), "%s: %s", #call, hipGetErrorString(e_));  \
+            pd_destroy(ctx);                                                         \
+            return PD_E_HIP;                                                         \
+        }                                                                            \
+    } while (0)
+    CRH(hipSetDevice(cfg->device_id));
+    CRH(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    const size_t B = cfg->max_batch, PK = cfg->max_peaks_per_part;
+    CR(dev_alloc(ctx, (void**)&ctx->raw, B * PD_N_PARTS * PK * sizeof(RawPeak)));
+    CR(dev_alloc(ctx, (void**)&ctx->raw_count, B * PD_N_PARTS * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->pk_y, B * PD_N_PARTS * PK * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->pk_x, B * PD_N_PARTS * PK * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->pk_id, B * PD_N_PARTS * PK * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->pk_score, B * PD_N_PARTS * PK * sizeof(double)));
+    CR(dev_alloc(ctx, (void**)&ctx->part_count, B * PD_N_PARTS * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->part_base, B * (PD_N_PARTS + 1) * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->pair_off, B * (PD_N_LIMBS + 1) * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->pair_score, B * (size_t)cfg->max_pairs_per_image * sizeof(double)));
+    CR(dev_alloc(ctx, (void**)&ctx->conn, B * PD_N_LIMBS * PK * sizeof(pd_conn)));
+    CR(dev_alloc(ctx, (void**)&ctx->conn_conf, B * PD_N_LIMBS * PK * 2 * sizeof(double)));
+    CR(dev_alloc(ctx, (void**)&ctx->limb_count, B * PD_N_LIMBS * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->persons, B * (size_t)cfg->max_persons * 20 * sizeof(double)));
+    CR(dev_alloc(ctx, (void**)&ctx->person_count, B * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->status, B * sizeof(int32_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->pack_off, (3 * (B + 1) + 4) * sizeof(int64_t)));
+    CR(dev_alloc(ctx, (void**)&ctx->packed_peaks, B * PD_N_PARTS * PK * sizeof(pd_peak)));
+    CR(dev_alloc(ctx, (void**)&ctx->packed_conns, B * PD_N_LIMBS * PK * sizeof(pd_conn)));
+    CR(dev_alloc(ctx, (void**)&ctx->packed_persons, B * (size_t)cfg->max_persons * 20 * sizeof(double)));
+    CRH(hipHostMalloc((void**)&ctx->host_totals, 4 * sizeof(int64_t), hipHostMallocDefault));
+    CRH(hipMemset(ctx->status, 0, B * sizeof(int32_t)));
+    if (cfg->fullres) {
+        const size_t n = (size_t)cfg->max_h * cfg->max_w;
+        CR(ensure(ctx, (void**)&ctx->full_heat, &ctx->full_heat_cap, B * PD_CH_HEAT * n * sizeof(double)));
+        CR(ensure(ctx, (void**)&ctx->full_paf, &ctx->full_paf_cap, B * PD_CH_PAF * n * sizeof(double)));
+    }
+#undef CR
+#undef CRH
+    *out = ctx;
+    return PD_OK;
+}
+
+extern "C" int pd_destroy(pd_ctx* ctx) {
+    PD_CHECK_CTX(ctx);
+    hipSetDevice(ctx->cfg.device_id);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    void* ptrs[] = {ctx->stage_heat, ctx->stage_paf, ctx->full_heat, ctx->full_paf, ctx->tmp_up, ctx->tmp_in,
+                    ctx->tmp_smooth, ctx->tmp_smooth2, ctx->tabs[0].i, ctx->tabs[0].f, ctx->tabs[1].i,
+                    ctx->tabs[1].f, ctx->tabs[2].i, ctx->tabs[2].f, ctx->raw, ctx->raw_count, ctx->pk_y,
+                    ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
+                    ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
+                    ctx->person_count, ctx->status, ctx->pack_off, ctx->packed_peaks, ctx->packed_conns,
+                    ctx->packed_persons};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (ctx->host_totals) hipHostFree(ctx->host_totals);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PD_OK;
+}
+
+extern "C" int pd_set_mode(pd_ctx* ctx, int mode) {
+    PD_CHECK_CTX(ctx);
+    if (mode != PD_MODE_P && mode != PD_MODE_D) PD_FAIL(ctx, PD_E_INVALID, "pd_set_mode: mode %d", mode);
+    ctx->mode = mode;
+    return PD_OK;
+}
+
+extern "C" int pd_set_impl(pd_ctx* ctx, int impl) {
+    PD_CHECK_CTX(ctx);
+    if (impl != PD_IMPL_FAST && impl != PD_IMPL_SIMPLE) PD_FAIL(ctx, PD_E_INVALID, "pd_set_impl: impl %d", impl);
+    ctx->impl = impl;
+    return PD_OK;
+}
+
+extern "C" void* pd_stream(pd_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+MapSource pd_heat_source(const pd_ctx* ctx) {
+    MapSource s;
+    memset(&s, 0, sizeof(s));
+    s.kind = ctx->src_kind;
+    s.h = ctx->h;
+    s.w = ctx->w;
+    s.H = ctx->H;
+    s.W = ctx->W;
+    s.lo = ctx->lo_heat;
+    s.C = PD_CH_HEAT;
+    s.full = ctx->full_heat;
+    s.Cfull = PD_CH_HEAT;
+    s.ty = ctx->tabs[0].ty;
+    s.tx = ctx->tabs[0].tx;
+    return s;
+}
+
+MapSource pd_paf_source(const pd_ctx* ctx) {
+    MapSource s = pd_heat_source(ctx);
+    s.lo = ctx->lo_paf;
+    s.C = PD_CH_PAF;
+    s.full = ctx->full_paf;
+    s.Cfull = PD_CH_PAF;
+    return s;
+}
+
+static void reset_results(pd_ctx* ctx) {
+    ctx->have_peaks = ctx->have_conns = ctx->have_persons = ctx->packed = 0;
+}
+
+static int check_batch(pd_ctx* ctx, int B, int H, int W, const char* who) {
+    if (B < 1 || B > ctx->cfg.max_batch) PD_FAIL(ctx, PD_E_INVALID, "%s: batch %d exceeds max_batch %d", who, B, ctx->cfg.max_batch);
+    if (H < 1 || W < 1 || H > ctx->cfg.max_h || W > ctx->cfg.max_w)
+        PD_FAIL(ctx, PD_E_INVALID, "%s: image %dx%d exceeds the context's %dx%d", who, H, W, ctx->cfg.max_h, ctx->cfg.max_w);
+    return PD_OK;
+}
+
+extern "C" int pd_set_lowres(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H,
+                             int W, int mem) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    int rc = check_batch(ctx, B, H, W, "pd_set_lowres");
+    if (rc != PD_OK) return rc;
+    if (h < 1 || w < 1 || H > 8 * h || W > 8 * w || H <= 8 * (h - 1) || W <= 8 * (w - 1))
+        PD_FAIL(ctx, PD_E_INVALID, "pd_set_lowres: %dx%d is not a crop of the x8 map of %dx%d", H, W, h, w);
+    if (!heat && !paf) PD_FAIL(ctx, PD_E_INVALID, "pd_set_lowres: no input");
+    const size_t nh = (size_t)B * h * w * PD_CH_HEAT, np = (size_t)B * h * w * PD_CH_PAF;
+    if (mem == PD_MEM_HOST) {
+        if (heat) {
+            rc = ensure(ctx, (void**)&ctx->stage_heat, &ctx->stage_heat_cap, nh * sizeof(float));
+            if (rc != PD_OK) return rc;
+            PD_HIP(ctx, hipMemcpyAsync(ctx->stage_heat, heat, nh * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            ctx->lo_heat = ctx->stage_heat;
+        }
+        if (paf) {
+            rc = ensure(ctx, (void**)&ctx->stage_paf, &ctx->stage_paf_cap, np * sizeof(float));
+            if (rc != PD_OK) return rc;
+            PD_HIP(ctx, hipMemcpyAsync(ctx->stage_paf, paf, np * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            ctx->lo_paf = ctx->stage_paf;
+        }
+    } else {
+        if (heat) ctx->lo_heat = heat;
+        if (paf) ctx->lo_paf = paf;
+    }
+    rc = pd_build_tables(ctx, h, w, H, W);
+    if (rc != PD_OK) return rc;
+    ctx->src_kind = PD_SRC_LOWRES;
+    ctx->B = B;
+    ctx->h = h;
+    ctx->w = w;
+    ctx->H = H;
+    ctx->W = W;
+    ctx->heat_f32 = 0;
+    reset_results(ctx);
+    return PD_OK;
+}
+
+static int ensure_full(pd_ctx* ctx, int B, int H, int W, bool heat, bool paf) {
+    const size_t n = (size_t)H * W;
+    int rc;
+    if (heat) {
+        rc = ensure(ctx, (void**)&ctx->full_heat, &ctx->full_heat_cap, (size_t)B * PD_CH_HEAT * n * sizeof(double));
+        if (rc != PD_OK) return rc;
+    }
+    if (paf) {
+        rc = ensure(ctx, (void**)&ctx->full_paf, &ctx->full_paf_cap, (size_t)B * PD_CH_PAF * n * sizeof(double));
+        if (rc != PD_OK) return rc;
+    }
+    return PD_OK;
+}
+
+extern "C" int pd_load_fullres(pd_ctx* ctx, const void* heat, int heat_dtype, int heat_channels,
+                               const void* paf, int paf_dtype, int paf_channels, int B, int H, int W, int mem) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    int rc = check_batch(ctx, B, H, W, "pd_load_fullres");
+    if (rc != PD_OK) return rc;
+    if (heat && heat_channels < PD_N_PARTS) PD_FAIL(ctx, PD_E_INVALID, "pd_load_fullres: heatmap needs >= 18 channels, got %d", heat_channels);
+    if (paf && paf_channels < PD_CH_PAF) PD_FAIL(ctx, PD_E_INVALID, "pd_load_fullres: pafs need >= 38 channels, got %d", paf_channels);
+    if (ctx->src_kind == PD_SRC_FULLRES && (ctx->B != B || ctx->H != H || ctx->W != W)) {
+        ctx->have_full_heat = ctx->have_full_paf = 0;
+    }
+    rc = ensure_full(ctx, B, H, W, heat != nullptr, paf != nullptr);
+    if (rc != PD_OK) return rc;
+    const size_t n = (size_t)H * W;
+    for (int which = 0; which < 2; ++which) {
+        const void* src = which == 0 ? heat : paf;
+        if (!src) continue;
+        const int dtype = which == 0 ? heat_dtype : paf_dtype;
+        const int C = which == 0 ? heat_channels : paf_channels;
+        const int Cdst = which == 0 ? PD_CH_HEAT : PD_CH_PAF;
+        double* dst = which == 0 ? ctx->full_heat : ctx->full_paf;
+        const size_t bytes = (size_t)B * n * C * (dtype == PD_F32 ? 4 : 8);
+        const void* dsrc = src;
+        if (mem == PD_MEM_HOST) {
+            rc = ensure(ctx, &ctx->tmp_in, &ctx->tmp_in_cap, bytes);
+            if (rc != PD_OK) return rc;
+            PD_HIP(ctx, hipMemcpyAsync(ctx->tmp_in, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+            dsrc = ctx->tmp_in;
+        }
+        rc = pd_launch_hwc_to_planar(ctx, dsrc, dtype, C, Cdst, B, H, W, dst);
+        if (rc != PD_OK) return rc;
+        if (which == 0) {
+            ctx->heat_f32 = dtype == PD_F32;
+            ctx->have_full_heat = 1;
+        } else {
+            ctx->have_full_paf = 1;
+        }
+    }
+    ctx->src_kind = PD_SRC_FULLRES;
+    ctx->B = B;
+    ctx->H = H;
+    ctx->W = W;
+    ctx->h = ctx->w = 0;
+    reset_results(ctx);
+    return PD_OK;
+}
+
+extern "C" int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* heat, const float* const* paf,
+                               const int32_t* hs, const int32_t* ws, const int32_t* crop_h,
+                               const int32_t* crop_w, int H, int W, int B, int mem) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    int rc = check_batch(ctx, B, H, W, "pd_upsample_avg");
+    if (rc != PD_OK) return rc;
+    if (n_scales < 1 || !heat || !paf || !hs || !ws || !crop_h || !crop_w) PD_FAIL(ctx, PD_E_INVALID, "pd_upsample_avg: bad arguments");
+    for (int m = 0; m < n_scales; ++m) {
+        if (hs[m] < 1 || ws[m] < 1 || crop_h[m] < 1 || crop_w[m] < 1 || crop_h[m] > 8 * hs[m] || crop_w[m] > 8 * ws[m])
+            PD_FAIL(ctx, PD_E_INVALID, "pd_upsample_avg: scale %d: crop %dx%d of x8 map of %dx%d", m, crop_h[m], crop_w[m], hs[m], ws[m]);
+    }
+    rc = ensure_full(ctx, B, H, W, true, true);
+    if (rc != PD_OK) return rc;
+    for (int m = 0; m < n_scales; ++m) {
+        const size_t n_lo = (size_t)B * hs[m] * ws[m];
+        const size_t n_up = (size_t)B * 64 * hs[m] * ws[m];
+        rc = ensure(ctx, (void**)&ctx->tmp_up, &ctx->tmp_up_cap, n_up * PD_CH_PAF * sizeof(float));
+        if (rc != PD_OK) return rc;
+        for (int which = 0; which < 2; ++which) {
+            const int C = which == 0 ? PD_CH_HEAT : PD_CH_PAF;
+            const float* src = which == 0 ? heat[m] : paf[m];
+            double* dst = which == 0 ? ctx->full_heat : ctx->full_paf;
+            if (mem == PD_MEM_HOST) {
+                float** st = which == 0 ? &ctx->stage_heat : &ctx->stage_paf;
+                size_t* cap = which == 0 ? &ctx->stage_heat_cap : &ctx->stage_paf_cap;
+                rc = ensure(ctx, (void**)st, cap, n_lo * C * sizeof(float));
+                if (rc != PD_OK) return rc;
+                PD_HIP(ctx, hipMemcpyAsync(*st, src, n_lo * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                src = *st;
+            }
+            rc = pd_launch_resize_up8(ctx, src, C, B, hs[m], ws[m], ctx->tmp_up);
+            if (rc != PD_OK) return rc;
+            rc = pd_launch_resize_accum(ctx, ctx->tmp_up, C, B, 8 * hs[m], 8 * ws[m], crop_h[m], crop_w[m], dst, H,
+                                        W, (float)n_scales, m == 0);
+            if (rc != PD_OK) return rc;
+        }
+    }
+    ctx->src_kind = PD_SRC_FULLRES;
+    ctx->B = B;
+    ctx->H = H;
+    ctx->W = W;
+    ctx->h = ctx->w = 0;
+    ctx->heat_f32 = 0;
+    ctx->have_full_heat = ctx->have_full_paf = 1;
+    reset_results(ctx);
+    return PD_OK;
+}
+
+extern "C" int pd_read_fullres(pd_ctx* ctx, double* heat_out, double* paf_out) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (ctx->src_kind != PD_SRC_FULLRES) PD_FAIL(ctx, PD_E_STATE, "pd_read_fullres: no full-resolution maps in the context");
+    const size_t n = (size_t)ctx->H * ctx->W;
+    for (int which = 0; which < 2; ++which) {
+        double* out = which == 0 ? heat_out : paf_out;
+        if (!out) continue;
+        const int C = which == 0 ? PD_CH_HEAT : PD_CH_PAF;
+        const double* src = which == 0 ? ctx->full_heat : ctx->full_paf;
+        const size_t bytes = (size_t)ctx->B * n * C * sizeof(double);
+        int rc = ensure(ctx, &ctx->tmp_in, &ctx->tmp_in_cap, bytes);
+        if (rc != PD_OK) return rc;
+        rc = pd_launch_planar_to_hwc(ctx, src, C, ctx->B, ctx->H, ctx->W, (double*)ctx->tmp_in);
+        if (rc != PD_OK) return rc;
+        PD_HIP(ctx, hipMemcpyAsync(out, ctx->tmp_in, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PD_OK;
+}
+
+extern "C" int pd_peaks(pd_ctx* ctx, double thre1) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (ctx->src_kind == PD_SRC_NONE) PD_FAIL(ctx, PD_E_STATE, "pd_peaks: no source set");
+    if (ctx->src_kind == PD_SRC_LOWRES && !ctx->lo_heat) PD_FAIL(ctx, PD_E_STATE, "pd_peaks: no heatmaps set");
+    if (ctx->src_kind == PD_SRC_FULLRES && !ctx->have_full_heat) PD_FAIL(ctx, PD_E_STATE, "pd_peaks: no heatmaps loaded");
+    int rc = pd_launch_smooth_nms(ctx, thre1, nullptr);
+    if (rc != PD_OK) return rc;
+    rc = pd_launch_sort_peaks(ctx);
+    if (rc != PD_OK) return rc;
+    ctx->have_peaks = 1;
+    ctx->have_conns = ctx->have_persons = ctx->packed = 0;
+    return PD_OK;
+}
+
+extern "C" int pd_debug_smoothed(pd_ctx* ctx, double* out) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (ctx->src_kind == PD_SRC_NONE || !out) PD_FAIL(ctx, PD_E_STATE, "pd_debug_smoothed: no source set");
+    const size_t bytes = (size_t)ctx->B * PD_N_PARTS * ctx->H * ctx->W * sizeof(double);
+    double* dev = nullptr;
+    PD_HIP(ctx, hipMalloc(&dev, bytes));
+    int rc = pd_launch_smooth_nms(ctx, 1e300, dev);
+    if (rc == PD_OK) {
+        hipError_t e = hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            snprintf(ctx->err, sizeof(ctx->err), "pd_debug_smoothed: %s", hipGetErrorString(e));
+            rc = PD_E_HIP;
+        }
+    }
+    hipFree(dev);
+    return rc;
+}
+
+extern "C" int pd_set_peaks(pd_ctx* ctx, const int32_t* counts, const int32_t* y, const int32_t* x,
+                            const double* score, const int32_t* id) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!counts) PD_FAIL(ctx, PD_E_INVALID, "pd_set_peaks: counts is NULL");
+    if (ctx->src_kind == PD_SRC_NONE) PD_FAIL(ctx, PD_E_STATE, "pd_set_peaks: set a source first (it fixes the image size)");
+    const int PK = ctx->cfg.max_peaks_per_part;
+    int32_t base[PD_N_PARTS + 1], pair_off[PD_N_LIMBS + 1];
+    int acc = 0;
+    for (int p = 0; p < PD_N_PARTS; ++p) {
+        if (counts[p] < 0) PD_FAIL(ctx, PD_E_INVALID, "pd_set_peaks: negative count");
+        if (counts[p] > PK) PD_FAIL(ctx, PD_E_OVERFLOW, "pd_set_peaks: %d peaks of part %d exceed max_peaks_per_part %d", counts[p], p, PK);
+        base[p] = acc;
+        acc += counts[p];
+    }
+    base[PD_N_PARTS] = acc;
+    long long pairs = 0;
+    for (int k = 0; k < PD_N_LIMBS; ++k) {
+        pair_off[k] = (int32_t)pairs;
+        pairs += (long long)counts[pd_limb_from(k)] * counts[pd_limb_to(k)];
+        if (pairs > ctx->cfg.max_pairs_per_image)
+            PD_FAIL(ctx, PD_E_OVERFLOW, "pd_set_peaks: %lld candidate pairs exceed max_pairs_per_image %d", pairs, ctx->cfg.max_pairs_per_image);
+    }
+    pair_off[PD_N_LIMBS] = (int32_t)pairs;
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < PD_N_PARTS; ++p) {
+        const size_t o = (size_t)p * PK, n = counts[p];
+        if (n == 0) continue;
+        PD_HIP(ctx, hipMemcpy(ctx->pk_y + o, y + base[p], n * sizeof(int32_t), hipMemcpyHostToDevice));
+        PD_HIP(ctx, hipMemcpy(ctx->pk_x + o, x + base[p], n * sizeof(int32_t), hipMemcpyHostToDevice));
+        PD_HIP(ctx, hipMemcpy(ctx->pk_score + o, score + base[p], n * sizeof(double), hipMemcpyHostToDevice));
+        PD_HIP(ctx, hipMemcpy(ctx->pk_id + o, id + base[p], n * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    PD_HIP(ctx, hipMemcpy(ctx->part_count, counts, sizeof(int32_t) * PD_N_PARTS, hipMemcpyHostToDevice));
+    PD_HIP(ctx, hipMemcpy(ctx->part_base, base, sizeof(base), hipMemcpyHostToDevice));
+    PD_HIP(ctx, hipMemcpy(ctx->pair_off, pair_off, sizeof(pair_off), hipMemcpyHostToDevice));
+    PD_HIP(ctx, hipMemset(ctx->status, 0, sizeof(int32_t)));
+    ctx->B = 1;
+    ctx->have_peaks = 1;
+    ctx->have_conns = ctx->have_persons = ctx->packed = 0;
+    return PD_OK;
+}
+
+extern "C" int pd_connections(pd_ctx* ctx, double thre2) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!ctx->have_peaks) PD_FAIL(ctx, PD_E_STATE, "pd_connections: no peaks (run pd_peaks or pd_set_peaks)");
+    if (ctx->src_kind == PD_SRC_LOWRES && !ctx->lo_paf) PD_FAIL(ctx, PD_E_STATE, "pd_connections: no PAFs set");
+    if (ctx->src_kind == PD_SRC_FULLRES && !ctx->have_full_paf) PD_FAIL(ctx, PD_E_STATE, "pd_connections: no PAFs loaded");
+    int rc = pd_launch_pairs(ctx, thre2);
+    if (rc != PD_OK) return rc;
+    rc = pd_launch_match(ctx);
+    if (rc != PD_OK) return rc;
+    ctx->have_conns = 1;
+    ctx->have_persons = ctx->packed = 0;
+    return PD_OK;
+}
+
+extern "C" int pd_set_connections(pd_ctx* ctx, const int32_t* counts, const double* rows) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!counts) PD_FAIL(ctx, PD_E_INVALID, "pd_set_connections: counts is NULL");
+    const int PK = ctx->cfg.max_peaks_per_part;
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t at = 0;
+    for (int k = 0; k < PD_N_LIMBS; ++k) {
+        const int n = counts[k];
+        if (n > PK) PD_FAIL(ctx, PD_E_OVERFLOW, "pd_set_connections: %d connections of limb %d exceed max_peaks_per_part %d", n, k, PK);
+        if (n <= 0) continue;
+        pd_conn* tmp = (pd_conn*)malloc(sizeof(pd_conn) * n);
+        double* cf = (double*)malloc(sizeof(double) * 2 * n);
+        if (!tmp || !cf) {
+            free(tmp);
+            free(cf);
+            PD_FAIL(ctx, PD_E_INVALID, "pd_set_connections: out of host memory");
+        }
+        for (int i = 0; i < n; ++i) {
+            const double* r = rows + (at + i) * 5;
+            tmp[i].id_a = (int32_t)r[0];  // int(connection[0]), utils/postprocess.py:188
+            tmp[i].id_b = (int32_t)r[1];
+            tmp[i].ia = tmp[i].ib = -1;
+            tmp[i].score = r[2];
+            cf[2 * i] = r[3];
+            cf[2 * i + 1] = r[4];
+        }
+        hipError_t e1 = hipMemcpy(ctx->conn + (size_t)k * PK, tmp, sizeof(pd_conn) * n, hipMemcpyHostToDevice);
+        hipError_t e2 = hipMemcpy(ctx->conn_conf + (size_t)k * PK * 2, cf, sizeof(double) * 2 * n, hipMemcpyHostToDevice);
+        free(tmp);
+        free(cf);
+        PD_HIP(ctx, e1);
+        PD_HIP(ctx, e2);
+        at += n;
+    }
+    PD_HIP(ctx, hipMemcpy(ctx->limb_count, counts, sizeof(int32_t) * PD_N_LIMBS, hipMemcpyHostToDevice));
+    PD_HIP(ctx, hipMemset(ctx->status, 0, sizeof(int32_t)));
+    ctx->B = 1;
+    ctx->have_conns = 1;
+    ctx->have_persons = ctx->packed = 0;
+    return PD_OK;
+}
+
+extern "C" int pd_parse(pd_ctx* ctx) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!ctx->have_conns) PD_FAIL(ctx, PD_E_STATE, "pd_parse: no connections (run pd_connections or pd_set_connections)");
+    int rc = pd_launch_parse(ctx);
+    if (rc != PD_OK) return rc;
+    ctx->have_persons = 1;
+    ctx->packed = 0;
+    return PD_OK;
+}
+
+extern "C" int pd_pack(pd_ctx* ctx) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!ctx->have_peaks && !ctx->have_conns && !ctx->have_persons) PD_FAIL(ctx, PD_E_STATE, "pd_pack: nothing to pack");
+    int rc = pd_launch_pack(ctx);
+    if (rc != PD_OK) return rc;
+    const int64_t* dev_totals = ctx->pack_off + 3 * ((size_t)ctx->cfg.max_batch + 1);
+    PD_HIP(ctx, hipMemcpyAsync(ctx->host_totals, dev_totals, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->packed = 1;
+    return PD_OK;
+}
+
+extern "C" int pd_decode_fullres(pd_ctx* ctx, double thre1, double thre2) {
+    int rc = pd_peaks(ctx, thre1);
+    if (rc != PD_OK) return rc;
+    rc = pd_connections(ctx, thre2);
+    if (rc != PD_OK) return rc;
+    rc = pd_parse(ctx);
+    if (rc != PD_OK) return rc;
+    return pd_pack(ctx);
+}
+
+extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H,
+                               int W, double thre1, double thre2, int mem) {
+    PD_CHECK_CTX(ctx);
+    if (!heat || !paf) PD_FAIL(ctx, PD_E_INVALID, "pd_decode_batch: heat and paf are required");
+    int rc = pd_set_lowres(ctx, heat, paf, B, h, w, H, W, mem);
+    if (rc != PD_OK) return rc;
+    return pd_decode_fullres(ctx, thre1, thre2);
+}
+
+extern "C" int pd_sync_totals(pd_ctx* ctx, pd_totals* totals) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!ctx->packed) PD_FAIL(ctx, PD_E_STATE, "pd_sync_totals: call pd_pack (or a decode entry point) first");
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (totals) {
+        totals->n_images = ctx->B;
+        totals->n_peaks = ctx->host_totals[0];
+        totals->n_conns = ctx->host_totals[1];
+        totals->n_persons = ctx->host_totals[2];
+        totals->first_bad_image = (int32_t)ctx->host_totals[3];
+    }
+    if (ctx->host_totals[3] >= 0) {
+        int32_t st = 0;
+        PD_HIP(ctx, hipMemcpy(&st, ctx->status + ctx->host_totals[3], sizeof(st), hipMemcpyDeviceToHost));
+        if (st == PD_E_INDEX)
+            PD_FAIL(ctx, PD_E_INDEX, "image %lld: a connection touches more than two persons (predict.py:199 IndexError)", (long long)ctx->host_totals[3]);
+        PD_FAIL(ctx, PD_E_OVERFLOW, "image %lld: a capacity of the context was exceeded (peaks per part %d, pairs %d, persons %d)",
+                (long long)ctx->host_totals[3], ctx->cfg.max_peaks_per_part, ctx->cfg.max_pairs_per_image, ctx->cfg.max_persons);
+    }
+    return PD_OK;
+}
+
+extern "C" int pd_fetch(pd_ctx* ctx, int32_t* part_count, int32_t* limb_count, int32_t* person_count,
+                        int32_t* status, pd_peak* peaks, pd_conn* conns, double* persons) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!ctx->packed) PD_FAIL(ctx, PD_E_STATE, "pd_fetch: call pd_pack (or a decode entry point) first");
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t B = ctx->B;
+    hipStream_t s = ctx->stream;
+    if (part_count && ctx->have_peaks)
+        PD_HIP(ctx, hipMemcpyAsync(part_count, ctx->part_count, B * PD_N_PARTS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (limb_count && ctx->have_conns)
+        PD_HIP(ctx, hipMemcpyAsync(limb_count, ctx->limb_count, B * PD_N_LIMBS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (person_count && ctx->have_persons)
+        PD_HIP(ctx, hipMemcpyAsync(person_count, ctx->person_count, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (status) PD_HIP(ctx, hipMemcpyAsync(status, ctx->status, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (peaks && ctx->have_peaks && ctx->host_totals[0] > 0)
+        PD_HIP(ctx, hipMemcpyAsync(peaks, ctx->packed_peaks, ctx->host_totals[0] * sizeof(pd_peak), hipMemcpyDeviceToHost, s));
+    if (conns && ctx->have_conns && ctx->host_totals[1] > 0)
+        PD_HIP(ctx, hipMemcpyAsync(conns, ctx->packed_conns, ctx->host_totals[1] * sizeof(pd_conn), hipMemcpyDeviceToHost, s));
+    if (persons && ctx->have_persons && ctx->host_totals[2] > 0)
+        PD_HIP(ctx, hipMemcpyAsync(persons, ctx->packed_persons, ctx->host_totals[2] * 20 * sizeof(double), hipMemcpyDeviceToHost, s));
+    PD_HIP(ctx, hipStreamSynchronize(s));
+    return PD_OK;
+}

@@ -1,0 +1,189 @@
+// Shared declarations of libposedecode (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/posedecode.h"
+
+// Every floating-point result on this path must be the separately rounded
+// multiply / add the CPU reference performs: no fused multiply-add anywhere.
+#pragma clang fp contract(off)
+
+#define PD_GR 12      // Gaussian radius: int(4.0 * 3 + 0.5)
+#define PD_GTAPS 13   // centre + 12 symmetric pairs
+#define PD_MID 10     // sample points per limb candidate (utils/postprocess.py:79)
+
+enum { PD_SRC_NONE = 0, PD_SRC_LOWRES = 1, PD_SRC_FULLRES = 2 };
+
+struct RawPeak {
+    int32_t y, x;
+    double score;
+};
+
+// Limb table, cfgs/config_vgg19.py:56-57.
+__host__ __device__ inline int pd_limb_from(int k) {
+    const int t[19] = {1, 8, 9, 1, 11, 12, 1, 2, 3, 2, 1, 5, 6, 5, 1, 0, 0, 14, 15};
+    return t[k];
+}
+__host__ __device__ inline int pd_limb_to(int k) {
+    const int t[19] = {8, 9, 10, 11, 12, 13, 2, 3, 4, 16, 5, 6, 7, 17, 0, 14, 15, 16, 17};
+    return t[k];
+}
+
+// Bicubic tap table of one axis: for destination index d the first source tap
+// (floor(s) - 1, unclamped) and the four float32 Keys weights (A = -0.75).
+struct CubicTable {
+    const int32_t* ofs;  // [n]
+    const float* coef;   // [n][4]
+};
+
+// Where the full-resolution heat / PAF values come from.
+struct MapSource {
+    int kind;             // PD_SRC_LOWRES or PD_SRC_FULLRES
+    int h, w;             // network-resolution size (lowres)
+    int H, W;             // full-resolution size
+    const float* lo;      // (B, h, w, C) float32
+    int C;                // channels of lo
+    const double* full;   // (B, Cfull, H, W) float64 planes
+    int Cfull;
+    CubicTable ty, tx;    // x8 tables of length H and W
+};
+
+struct TableSlot {
+    int32_t* i;
+    float* f;
+    size_t cap;
+    CubicTable ty, tx;
+};
+
+struct pd_ctx {
+    pd_config cfg;
+    int mode, impl;
+    hipStream_t stream;
+    char err[512];
+
+    // ---- current source ----
+    int src_kind;
+    int B, h, w, H, W;
+    int heat_f32;  // full-res heat came from float32 data: round after each filter axis
+    const float* lo_heat;
+    const float* lo_paf;
+    float* stage_heat;  // staging for host-resident network outputs
+    float* stage_paf;
+    size_t stage_heat_cap, stage_paf_cap;
+    double* full_heat;  // (B, 19, H, W)
+    double* full_paf;   // (B, 38, H, W)
+    size_t full_heat_cap, full_paf_cap;
+    int have_full_heat, have_full_paf;
+    float* tmp_up;  // x8 maps of one scale, planar float32
+    size_t tmp_up_cap;
+    void* tmp_in;  // staging for host-resident full-resolution input
+    size_t tmp_in_cap;
+    double* tmp_smooth;  // (B, 18, H, W) scratch of the simple path / debug hook
+    size_t tmp_smooth_cap;
+    double* tmp_smooth2;
+    size_t tmp_smooth2_cap;
+
+    // bicubic tap tables on the device: slot 0 = x8 tables of the fused low-res
+    // source, slot 1 / 2 = first / second resize of pd_upsample_avg
+    TableSlot tabs[3];
+    int tab_h, tab_w, tab_H, tab_W;  // what the slot-0 tables were built for
+
+    // ---- peaks ----
+    RawPeak* raw;        // [B][18][PK] unordered
+    int32_t* raw_count;  // [B][18]
+    int32_t *pk_y, *pk_x, *pk_id;  // [B][18][PK] sorted (y, x) ascending
+    double* pk_score;
+    int32_t* part_count;  // [B][18]
+    int32_t* part_base;   // [B][19] exclusive prefix of part_count
+    int32_t* pair_off;    // [B][20] exclusive prefix over limbs of nA*nB
+    double* pair_score;   // [B][max_pairs] ; < 0 = rejected
+    // ---- connections ----
+    pd_conn* conn;        // [B][19][PK]
+    double* conn_conf;    // [B][19][PK][2]
+    int32_t* limb_count;  // [B][19], -1 = special
+    // ---- persons ----
+    double* persons;        // [B][max_persons][20]
+    int32_t* person_count;  // [B]
+    int32_t* status;        // [B]
+    // ---- packed results ----
+    int64_t* pack_off;  // [3][B+1] exclusive prefixes: peaks, conns, persons
+    pd_peak* packed_peaks;
+    pd_conn* packed_conns;
+    double* packed_persons;
+    int64_t* host_totals;  // pinned: [3] totals + first_bad
+    int have_peaks, have_conns, have_persons, packed;
+};
+
+#define PD_FAIL(ctx, code, ...)                                  \
+    do {                                                         \
+        snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__);   \
+        return (code);                                           \
+    } while (0)
+
+#define PD_HIP(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call,   \
+                     hipGetErrorString(e_), __FILE__, __LINE__);                       \
+            return PD_E_HIP;                                                           \
+        }                                                                              \
+    } while (0)
+
+// ---- device helpers shared by the kernels -------------------------------------
+
+__device__ __forceinline__ int pd_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// scipy mode='reflect' index (d c b a | a b c d | d c b a) for any offset.
+__device__ __forceinline__ int pd_reflect(int i, int n) {
+    if (i >= 0 && i < n) return i;
+    int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i >= n ? p - 1 - i : i;
+}
+
+// One bicubic sample of channel ch of a (h, w, C) float32 map at full-resolution
+// (Y, X): horizontal 4-tap sums of four source rows, then the vertical 4-tap sum,
+// each evaluated left to right in float32 with clamped taps (OpenCV resize order).
+__device__ __forceinline__ float pd_bicubic_at(const float* __restrict__ img, int h, int w, int C,
+                                               int ch, int Y, int X, const CubicTable& ty,
+                                               const CubicTable& tx) {
+    const int x0 = tx.ofs[X];
+    const int y0 = ty.ofs[Y];
+    const float a0 = tx.coef[4 * X + 0], a1 = tx.coef[4 * X + 1], a2 = tx.coef[4 * X + 2],
+                a3 = tx.coef[4 * X + 3];
+    const int xi0 = pd_clampi(x0, 0, w - 1), xi1 = pd_clampi(x0 + 1, 0, w - 1),
+              xi2 = pd_clampi(x0 + 2, 0, w - 1), xi3 = pd_clampi(x0 + 3, 0, w - 1);
+    float hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int s = pd_clampi(y0 + k, 0, h - 1);
+        const float* row = img + ((size_t)s * w) * C + ch;
+        hv[k] = ((row[(size_t)xi0 * C] * a0 + row[(size_t)xi1 * C] * a1) + row[(size_t)xi2 * C] * a2) +
+                row[(size_t)xi3 * C] * a3;
+    }
+    return ((hv[0] * ty.coef[4 * Y + 0] + hv[1] * ty.coef[4 * Y + 1]) + hv[2] * ty.coef[4 * Y + 2]) +
+           hv[3] * ty.coef[4 * Y + 3];
+}
+
+// ---- stage launchers (defined in the .hip files) --------------------------------
+int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed);
+int pd_launch_sort_peaks(pd_ctx* ctx);
+int pd_launch_pairs(pd_ctx* ctx, double thre2);
+int pd_launch_match(pd_ctx* ctx);
+int pd_launch_parse(pd_ctx* ctx);
+int pd_launch_pack(pd_ctx* ctx);
+int pd_launch_resize_up8(pd_ctx* ctx, const float* src, int C, int B, int hs, int ws, float* dst);
+int pd_launch_resize_accum(pd_ctx* ctx, const float* up, int C, int B, int Hs, int Ws, int crop_h,
+                           int crop_w, double* dst, int H, int W, float n_scales, int first);
+int pd_launch_hwc_to_planar(pd_ctx* ctx, const void* src, int dtype, int Csrc, int Cdst, int B, int H,
+                            int W, double* dst);
+int pd_launch_planar_to_hwc(pd_ctx* ctx, const double* src, int C, int B, int H, int W, double* dst);
+int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W);
+void pd_host_cubic_table(int src_len, int dst_len, double scale, int32_t* ofs, float* coef);
+MapSource pd_heat_source(const pd_ctx* ctx);
+MapSource pd_paf_source(const pd_ctx* ctx);

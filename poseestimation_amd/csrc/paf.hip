@@ -1,0 +1,373 @@
+// PAF line-integral scoring of every limb candidate pair and the per-limb greedy
+// matching: get_connections of utils/postprocess.py:78-160 (twin predict.py:120-174).
+//
+// Per pair (a, b) of limb k, in float64 with separately rounded operations:
+//   step = (b - a) / 9;  p_i = i * step + a  (p_9 = b)             np.linspace, :121-122
+//   index = trunc(p_i) [mode P, :123]  |  rint(p_i), half-even [mode D, predict.py:147]
+//   mid_i = v0 * u0 + v1 * u1                                        :128
+//   score = ((((0 + mid_0) + mid_1) + ..) + mid_9) / 10 + min(0.5 * H / norm - 1, 0)   :129
+//   kept iff count(mid_i > thre2) >= 9 and score > 0                 :131-136
+// Candidates are taken in descending score order, ties in a-major / b-minor order
+// (stable sort, :141), a peak being used at most once per side (:144-156).
+#include <math.h>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+struct PairArgs {
+    MapSource src;  // PAF source
+    int mode;
+    double thr;
+    const int32_t* pk_y;
+    const int32_t* pk_x;
+    const int32_t* part_count;
+    const int32_t* pair_off;
+    int PK;
+    int max_pairs;
+    double* pair_score;
+};
+
+// Two adjacent channels (ch, ch+1) of a (h, w, C) float32 map, bicubic at (Y, X);
+// same arithmetic as pd_bicubic_at.
+__device__ __forceinline__ void bicubic2_at(const float* __restrict__ img, int h, int w, int C, int ch, int Y,
+                                            int X, const CubicTable& ty, const CubicTable& tx, float* o0,
+                                            float* o1) {
+    const int x0 = tx.ofs[X];
+    const int y0 = ty.ofs[Y];
+    const float a0 = tx.coef[4 * X + 0], a1 = tx.coef[4 * X + 1], a2 = tx.coef[4 * X + 2],
+                a3 = tx.coef[4 * X + 3];
+    const size_t xi0 = (size_t)pd_clampi(x0, 0, w - 1) * C, xi1 = (size_t)pd_clampi(x0 + 1, 0, w - 1) * C,
+                 xi2 = (size_t)pd_clampi(x0 + 2, 0, w - 1) * C, xi3 = (size_t)pd_clampi(x0 + 3, 0, w - 1) * C;
+    float h0[4], h1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* row = img + ((size_t)pd_clampi(y0 + k, 0, h - 1) * w) * C + ch;
+        h0[k] = ((row[xi0] * a0 + row[xi1] * a1) + row[xi2] * a2) + row[xi3] * a3;
+        h1[k] = ((row[xi0 + 1] * a0 + row[xi1 + 1] * a1) + row[xi2 + 1] * a2) + row[xi3 + 1] * a3;
+    }
+    const float b0 = ty.coef[4 * Y + 0], b1 = ty.coef[4 * Y + 1], b2 = ty.coef[4 * Y + 2],
+                b3 = ty.coef[4 * Y + 3];
+    *o0 = ((h0[0] * b0 + h0[1] * b1) + h0[2] * b2) + h0[3] * b3;
+    *o1 = ((h1[0] * b0 + h1[1] * b1) + h1[2] * b2) + h1[3] * b3;
+}
+
+// 16 lanes per candidate pair: lanes 0..9 take one sample point each, then the ten
+// products are summed in sample order.
+__global__ void __launch_bounds__(256)
+k_pair_scores(PairArgs a) {
+    __shared__ int32_t s_off[PD_N_LIMBS + 1];
+    __shared__ int32_t s_cnt[PD_N_PARTS];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid <= PD_N_LIMBS) s_off[tid] = a.pair_off[b * (PD_N_LIMBS + 1) + tid];
+    if (tid < PD_N_PARTS) s_cnt[tid] = a.part_count[b * PD_N_PARTS + tid];
+    __syncthreads();
+    const int total = s_off[PD_N_LIMBS];
+    const int group = tid >> 4;
+    const int i = tid & 15;
+    const int lane = tid & 63;
+    const int H = a.src.H, W = a.src.W;
+    const size_t npx = (size_t)H * W;
+    for (int base = blockIdx.x * 16; base < total; base += gridDim.x * 16) {
+        const int p = base + group;
+        const bool active = p < total;
+        double mid = 0.0, u0 = 0.0, u1 = 0.0, norm = 1.0;
+        bool skip = true;
+        if (active) {
+            int k = 0;
+            while (p >= s_off[k + 1]) ++k;
+            const int pa = pd_limb_from(k), pb = pd_limb_to(k);
+            const int nB = s_cnt[pb];
+            const int local = p - s_off[k];
+            const int ia = local / nB, ib = local - ia * nB;
+            const size_t oa = ((size_t)b * PD_N_PARTS + pa) * a.PK + ia;
+            const size_t ob = ((size_t)b * PD_N_PARTS + pb) * a.PK + ib;
+            const int ya = a.pk_y[oa], xa = a.pk_x[oa], yb = a.pk_y[ob], xb = a.pk_x[ob];
+            const long long dy = (long long)yb - ya, dx = (long long)xb - xa;
+            const double d2 = (double)(dy * dy + dx * dx);
+            norm = sqrt(d2);
+            double uy, ux;
+            if (a.mode == PD_MODE_P) {
+                skip = d2 == 0.0;  // coincident peaks, utils/postprocess.py:112
+                uy = (double)dy / norm;
+                ux = (double)dx / norm;
+            } else {
+                skip = false;
+                norm = fmax(norm, 1e-5);  // predict.py:141
+                uy = (double)dy / norm;
+                ux = (double)dx / norm;
+            }
+            if (!skip && i < PD_MID) {
+                double py, px;
+                if (i == PD_MID - 1) {
+                    py = (double)yb;
+                    px = (double)xb;
+                } else {
+                    const double sy = (double)dy / 9.0, sx = (double)dx / 9.0;
+                    py = (double)i * sy + (double)ya;
+                    px = (double)i * sx + (double)xa;
+                }
+                int iy, ix;
+                if (a.mode == PD_MODE_P) {
+                    iy = (int)py;
+                    ix = (int)px;
+                } else {
+                    iy = (int)rint(py);
+                    ix = (int)rint(px);
+                }
+                iy = pd_clampi(iy, 0, H - 1);
+                ix = pd_clampi(ix, 0, W - 1);
+                double v0, v1;
+                if (a.src.kind == PD_SRC_LOWRES) {
+                    float f0, f1;
+                    bicubic2_at(a.src.lo + (size_t)b * a.src.h * a.src.w * a.src.C, a.src.h, a.src.w, a.src.C,
+                                2 * k, iy, ix, a.src.ty, a.src.tx, &f0, &f1);
+                    v0 = (double)f0;
+                    v1 = (double)f1;
+                } else {
+                    const double* pl = a.src.full + ((size_t)b * a.src.Cfull + 2 * k) * npx + (size_t)iy * W + ix;
+                    v0 = pl[0];
+                    v1 = pl[npx];
+                }
+                if (a.mode == PD_MODE_P) {  // channel 2k pairs with dy, 2k+1 with dx
+                    u0 = uy;
+                    u1 = ux;
+                } else {                    // channel 2k pairs with dx, 2k+1 with dy
+                    u0 = ux;
+                    u1 = uy;
+                }
+                mid = v0 * u0 + v1 * u1;
+            }
+        }
+        // sequential sum over the ten samples of this group, as builtin sum() does
+        const int g0 = lane & 48;
+        double acc = 0.0 + __shfl(mid, g0);
+#pragma unroll
+        for (int s = 1; s < PD_MID; ++s) acc = acc + __shfl(mid, g0 + s);
+        const unsigned long long above = __ballot(i < PD_MID && mid > a.thr);
+        const int n_above = __builtin_popcountll((above >> g0) & 0xFFFFull);
+        if (active && i == 0) {
+            double out = -1.0;
+            if (!skip) {
+                const double prior = fmin(0.5 * (double)H / norm - 1.0, 0.0);
+                const double score = acc / 10.0 + prior;
+                if (n_above > 8 && score > 0.0) out = score;
+            }
+            a.pair_score[(size_t)b * a.max_pairs + p] = out;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Matching: one wavefront per (image, limb).
+// ---------------------------------------------------------------------------------
+struct MatchArgs {
+    int PK, max_pairs, cap;  // cap: candidates sorted in LDS (power of two)
+    const double* pair_score;
+    const int32_t* pair_off;
+    const int32_t* part_count;
+    const int32_t* pk_id;
+    const double* pk_score;
+    pd_conn* conn;
+    double* conn_conf;
+    int32_t* limb_count;
+};
+
+__device__ __forceinline__ bool cand_before(double sa, int ia, double sb, int ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+__global__ void __launch_bounds__(64)
+k_match(MatchArgs a) {
+    extern __shared__ __align__(16) unsigned char dyn[];
+    double* s_score = (double*)dyn;
+    int32_t* s_idx = (int32_t*)(dyn + (size_t)a.cap * 8);
+    unsigned char* usedA = dyn + (size_t)a.cap * 12;
+    unsigned char* usedB = usedA + a.PK;
+    const int k = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int pa = pd_limb_from(k), pb = pd_limb_to(k);
+    const int nA = a.part_count[b * PD_N_PARTS + pa], nB = a.part_count[b * PD_N_PARTS + pb];
+    int32_t* out_count = a.limb_count + b * PD_N_LIMBS + k;
+    if (nA == 0 || nB == 0) {  // utils/postprocess.py:92-95
+        if (lane == 0) *out_count = -1;
+        return;
+    }
+    const int off = a.pair_off[b * (PD_N_LIMBS + 1) + k];
+    const int npairs = a.pair_off[b * (PD_N_LIMBS + 1) + k + 1] - off;
+    const double* ps = a.pair_score + (size_t)b * a.max_pairs + off;
+    for (int i = lane; i < a.PK; i += 64) {
+        usedA[i] = 0;
+        usedB[i] = 0;
+    }
+    // compact the surviving candidates, keeping a-major / b-minor order
+    int total = 0;
+    for (int base = 0; base < npairs; base += 64) {
+        const int i = base + lane;
+        const double s = i < npairs ? ps[i] : -1.0;
+        const bool ok = s > 0.0;
+        const unsigned long long m = __ballot(ok);
+        const int pos = total + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (ok && pos < a.cap) {
+            s_score[pos] = s;
+            s_idx[pos] = i;
+        }
+        total += __builtin_popcountll(m);
+    }
+    const int limit = nA < nB ? nA : nB;
+    pd_conn* rows = a.conn + ((size_t)b * PD_N_LIMBS + k) * a.PK;
+    double* conf = a.conn_conf + ((size_t)b * PD_N_LIMBS + k) * a.PK * 2;
+    const int32_t* idA = a.pk_id + ((size_t)b * PD_N_PARTS + pa) * a.PK;
+    const int32_t* idB = a.pk_id + ((size_t)b * PD_N_PARTS + pb) * a.PK;
+    const double* scA = a.pk_score + ((size_t)b * PD_N_PARTS + pa) * a.PK;
+    const double* scB = a.pk_score + ((size_t)b * PD_N_PARTS + pb) * a.PK;
+    int count = 0;
+    __syncthreads();
+    if (total <= a.cap) {
+        // wave-level bitonic sort on (score descending, pair index ascending)
+        int n2 = 64;
+        while (n2 < total) n2 <<= 1;
+        for (int i = total + lane; i < n2; i += 64) {
+            s_score[i] = -INFINITY;
+            s_idx[i] = 0x7fffffff;
+        }
+        __syncthreads();
+        for (int kk = 2; kk <= n2; kk <<= 1) {
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < n2; t += 64) {
+                    const int q = t ^ j;
+                    if (q > t) {
+                        const double st = s_score[t], sq = s_score[q];
+                        const int it = s_idx[t], iq = s_idx[q];
+                        const bool fwd = (t & kk) == 0;
+                        const bool t_first = cand_before(st, it, sq, iq);
+                        if (fwd ? !t_first : t_first) {
+                            s_score[t] = sq;
+                            s_idx[t] = iq;
+                            s_score[q] = st;
+                            s_idx[q] = it;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // greedy pick, 64 sorted candidates at a time: the first lane whose two
+        // peaks are still free wins, then the others re-check
+        for (int base = 0; base < total && count < limit; base += 64) {
+            const int i = base + lane;
+            bool have = i < total;
+            const int idx = have ? s_idx[i] : 0;
+            const double sc = have ? s_score[i] : 0.0;
+            const int ia = idx / nB, ib = idx - ia * nB;
+            while (count < limit) {
+                const bool ok = have && !usedA[ia] && !usedB[ib];
+                const unsigned long long m = __ballot(ok);
+                if (m == 0ull) break;
+                const int first = __builtin_ctzll(m);
+                if (lane == first) {
+                    pd_conn r;
+                    r.id_a = idA[ia];
+                    r.id_b = idB[ib];
+                    r.ia = ia;
+                    r.ib = ib;
+                    r.score = sc;
+                    rows[count] = r;
+                    conf[2 * count] = scA[ia];
+                    conf[2 * count + 1] = scB[ib];
+                    usedA[ia] = 1;
+                    usedB[ib] = 1;
+                    have = false;
+                }
+                ++count;
+                __syncthreads();
+            }
+        }
+    } else {
+        // more survivors than the LDS list holds: repeated arg-max over the pair
+        // scores in memory (the same picks as sort + greedy, in the same order)
+        while (count < limit) {
+            double best = -1.0;
+            int best_i = 0x7fffffff;
+            for (int i = lane; i < npairs; i += 64) {
+                const double s = ps[i];
+                if (s > 0.0) {
+                    const int ia = i / nB, ib = i - ia * nB;
+                    if (!usedA[ia] && !usedB[ib] && cand_before(s, i, best, best_i)) {
+                        best = s;
+                        best_i = i;
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double os = __shfl_xor(best, d);
+                const int oi = __shfl_xor(best_i, d);
+                if (cand_before(os, oi, best, best_i)) {
+                    best = os;
+                    best_i = oi;
+                }
+            }
+            if (!(best > 0.0)) break;
+            const int ia = best_i / nB, ib = best_i - ia * nB;
+            if (lane == 0) {
+                pd_conn r;
+                r.id_a = idA[ia];
+                r.id_b = idB[ib];
+                r.ia = ia;
+                r.ib = ib;
+                r.score = best;
+                rows[count] = r;
+                conf[2 * count] = scA[ia];
+                conf[2 * count + 1] = scB[ib];
+                usedA[ia] = 1;
+                usedB[ib] = 1;
+            }
+            ++count;
+            __syncthreads();
+        }
+    }
+    if (lane == 0) *out_count = count;
+}
+
+int pd_launch_pairs(pd_ctx* ctx, double thre2) {
+    PairArgs a;
+    a.src = pd_paf_source(ctx);
+    a.mode = ctx->mode;
+    a.thr = thre2;
+    a.pk_y = ctx->pk_y;
+    a.pk_x = ctx->pk_x;
+    a.part_count = ctx->part_count;
+    a.pair_off = ctx->pair_off;
+    a.PK = ctx->cfg.max_peaks_per_part;
+    a.max_pairs = ctx->cfg.max_pairs_per_image;
+    a.pair_score = ctx->pair_score;
+    int per_image = (ctx->cfg.max_pairs_per_image + 15) / 16;
+    if (per_image > 64) per_image = 64;
+    hipLaunchKernelGGL(k_pair_scores, dim3(per_image, ctx->B), dim3(256), 0, ctx->stream, a);
+    PD_HIP(ctx, hipGetLastError());
+    return PD_OK;
+}
+
+extern int pd_match_cap_override;
+int pd_match_cap_override = 0;
+
+int pd_launch_match(pd_ctx* ctx) {
+    MatchArgs a;
+    a.PK = ctx->cfg.max_peaks_per_part;
+    a.max_pairs = ctx->cfg.max_pairs_per_image;
+    a.cap = pd_match_cap_override > 0 ? pd_match_cap_override : 2048;
+    a.pair_score = ctx->pair_score;
+    a.pair_off = ctx->pair_off;
+    a.part_count = ctx->part_count;
+    a.pk_id = ctx->pk_id;
+    a.pk_score = ctx->pk_score;
+    a.conn = ctx->conn;
+    a.conn_conf = ctx->conn_conf;
+    a.limb_count = ctx->limb_count;
+    const size_t lds = (size_t)a.cap * 12 + 2 * (size_t)a.PK;
+    hipLaunchKernelGGL(k_match, dim3(PD_N_LIMBS, ctx->B), dim3(64), lds, ctx->stream, a);
+    PD_HIP(ctx, hipGetLastError());
+    return PD_OK;
+}

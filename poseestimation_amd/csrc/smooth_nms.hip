@@ -1,0 +1,388 @@
+// Gaussian smoothing (sigma = 3, radius 12, reflect) + 4-neighbour NMS + peak
+// emission: get_peaks of utils/postprocess.py:26-75 (twin predict.py:88-111).
+//
+// Bit-exactness contract (scipy correlate1d, symmetric-kernel branch): per output
+//   t = x[c] * w[12];  for d = 12 .. 1:  t += (x[c-d] + x[c+d]) * w[12-d]
+// in float64 with separately rounded multiply and add, axis 0 (y) first, then
+// axis 1 (x); borders by half-sample reflection; a float32 source is rounded to
+// float32 after each axis.  NMS compares with >= against the four neighbours,
+// out-of-image neighbours count as 0.0, and requires value > threshold.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+// scipy _gaussian_kernel1d(sigma=3, order=0, radius=12): weights of distance
+// 12, 11, .. 1, 0 (index 12 = centre).
+__constant__ double c_gw[PD_GTAPS] = {
+    0x1.763a210dfb306p-15, 0x1.4fbe39149e277p-13, 0x1.0d8a5ad43c165p-11, 0x1.8345966f69518p-10,
+    0x1.f1e9915139406p-9,  0x1.1e6bccad344bap-7,  0x1.26defcaeb0202p-6,  0x1.0fa58939b528fp-5,
+    0x1.bfde9c12bec92p-5,  0x1.4a614d1afd337p-4,  0x1.b42a57d56c0bep-4,  0x1.01a25f86eb137p-3,
+    0x1.105a329f98197p-3};
+
+struct SmoothArgs {
+    MapSource src;
+    double thr;
+    int f32mode;
+    int n_strips, strip_w;
+    RawPeak* raw;
+    int32_t* raw_count;
+    int PK;
+    double* dbg;  // optional (B, 18, H, W)
+};
+
+__device__ __forceinline__ void emit_peak(bool is_peak, int y, int x, double score, RawPeak* list,
+                                          int32_t* count, int PK) {
+    const unsigned long long m = __ballot(is_peak);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(count, (int)__builtin_popcountll(m));
+    base = __shfl(base, (int)__builtin_ctzll(m));
+    if (is_peak) {
+        const int pos = base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (pos < PK) {
+            RawPeak p;
+            p.y = y;
+            p.x = x;
+            p.score = score;
+            list[pos] = p;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Streaming kernel: one workgroup owns one (image, part, column strip) and marches
+// down the rows.  Thread t owns column xs + t: the 25-row window of the unsmoothed
+// map lives in its registers (slot = row mod 25, made static by unrolling 25 row
+// steps), so the y pass needs no memory at all; the y-pass row goes through LDS
+// once for the x pass, and the last three smoothed rows stay in registers for NMS.
+// ---------------------------------------------------------------------------------
+#define NTMAX 512
+
+template <int SRC>
+struct ColLoader;
+
+// Upsampled-on-the-fly column of a (h, w, C) float32 network output.
+template <>
+struct ColLoader<PD_SRC_LOWRES> {
+    const float* img;  // image b, channel offset applied
+    int h, w, C;
+    const int32_t* yofs;
+    const float* ycoef;
+    int xi0, xi1, xi2, xi3;
+    float a0, a1, a2, a3;
+    int cur;  // first tap row the cached horizontal sums belong to
+    float hv[4];
+
+    __device__ __forceinline__ float hrow(int s) const {
+        s = pd_clampi(s, 0, h - 1);
+        const float* row = img + ((size_t)s * w) * C;
+        return ((row[(size_t)xi0 * C] * a0 + row[(size_t)xi1 * C] * a1) + row[(size_t)xi2 * C] * a2) +
+               row[(size_t)xi3 * C] * a3;
+    }
+    __device__ __forceinline__ void init(const MapSource& s, int b, int ch, int col) {
+        img = s.lo + (size_t)b * s.h * s.w * s.C + ch;
+        h = s.h;
+        w = s.w;
+        C = s.C;
+        yofs = s.ty.ofs;
+        ycoef = s.ty.coef;
+        const int x0 = s.tx.ofs[col];
+        xi0 = pd_clampi(x0, 0, w - 1);
+        xi1 = pd_clampi(x0 + 1, 0, w - 1);
+        xi2 = pd_clampi(x0 + 2, 0, w - 1);
+        xi3 = pd_clampi(x0 + 3, 0, w - 1);
+        a0 = s.tx.coef[4 * col + 0];
+        a1 = s.tx.coef[4 * col + 1];
+        a2 = s.tx.coef[4 * col + 2];
+        a3 = s.tx.coef[4 * col + 3];
+        cur = -1000000;
+    }
+    __device__ __forceinline__ double load(int r) {
+        const int y0 = yofs[r];
+        if (y0 == cur + 1) {
+            hv[0] = hv[1];
+            hv[1] = hv[2];
+            hv[2] = hv[3];
+            hv[3] = hrow(y0 + 3);
+        } else if (y0 != cur) {
+            hv[0] = hrow(y0);
+            hv[1] = hrow(y0 + 1);
+            hv[2] = hrow(y0 + 2);
+            hv[3] = hrow(y0 + 3);
+        }
+        cur = y0;
+        const float v = ((hv[0] * ycoef[4 * r + 0] + hv[1] * ycoef[4 * r + 1]) + hv[2] * ycoef[4 * r + 2]) +
+                        hv[3] * ycoef[4 * r + 3];
+        return (double)v;
+    }
+};
+
+// Column of a float64 plane.
+template <>
+struct ColLoader<PD_SRC_FULLRES> {
+    const double* col;
+    int W;
+    __device__ __forceinline__ void init(const MapSource& s, int b, int ch, int c) {
+        col = s.full + ((size_t)b * s.Cfull + ch) * (size_t)s.H * s.W + c;
+        W = s.W;
+    }
+    __device__ __forceinline__ double load(int r) const { return col[(size_t)r * W]; }
+};
+
+__device__ __forceinline__ double round_store(double v, int f32mode) {
+    return f32mode ? (double)(float)v : v;
+}
+
+struct RowState {
+    double s_prev1, s_prev2;  // smoothed rows y-1, y-2 of this column
+};
+
+template <int SRC, int S>
+__device__ __forceinline__ void row_step(const SmoothArgs& a, ColLoader<SRC>& ld, double (&win)[25],
+                                         RowState& st, double* ybuf, double* sbuf, int y, int H, int W,
+                                         int c, int xs, int xe, bool col_active, bool do_x, bool do_nms,
+                                         RawPeak* list, int32_t* count, double* dbg_plane) {
+    const int tid = threadIdx.x;
+    const int par = y & 1;
+    double* yrow = ybuf + par * (NTMAX + 2 * PD_GR);
+    if (y < H) {
+        if (col_active) {
+            int rn = y + PD_GR;
+            if (rn >= H) rn = 2 * H - 1 - rn;
+            win[(S + 12) % 25] = ld.load(rn);
+            double t = win[S] * c_gw[12];
+#pragma unroll
+            for (int d = 12; d >= 1; --d) t += (win[(S + 25 - d) % 25] + win[(S + d) % 25]) * c_gw[12 - d];
+            t = round_store(t, a.f32mode);
+            yrow[tid + PD_GR] = t;
+            // mirrored halo so the x pass reads straight offsets
+            if (xs == 0 && c < PD_GR) yrow[PD_GR - 1 - c] = t;
+            if (xe == W && c >= W - PD_GR) yrow[(2 * W - 1 - c) - xs + PD_GR] = t;
+        }
+    }
+    __syncthreads();
+    double s = 0.0;
+    if (y < H && do_x) {
+        const double* p = yrow + tid + PD_GR;
+        s = p[0] * c_gw[12];
+#pragma unroll
+        for (int d = 12; d >= 1; --d) s += (p[-d] + p[d]) * c_gw[12 - d];
+        s = round_store(s, a.f32mode);
+        if (dbg_plane != nullptr && do_nms) dbg_plane[(size_t)y * W + c] = s;
+    }
+    sbuf[par * (NTMAX + 2) + tid + 1] = s;
+    if (y >= 1) {
+        bool is_peak = false;
+        const double m = st.s_prev1;
+        if (do_nms) {
+            const double* srow = sbuf + (par ^ 1) * (NTMAX + 2);
+            const double left = (c == 0) ? 0.0 : srow[tid];
+            const double right = (c == W - 1) ? 0.0 : srow[tid + 2];
+            const double up = (y == 1) ? 0.0 : st.s_prev2;
+            const double down = (y == H) ? 0.0 : s;
+            is_peak = (m >= up) && (m >= down) && (m >= left) && (m >= right) && (m > a.thr);
+        }
+        emit_peak(is_peak, y - 1, c, win[(S + 24) % 25], list, count, a.PK);
+    }
+    st.s_prev2 = st.s_prev1;
+    st.s_prev1 = s;
+}
+
+template <int SRC>
+__global__ void __launch_bounds__(NTMAX)
+k_smooth_nms_stream(SmoothArgs a) {
+    __shared__ double ybuf[2 * (NTMAX + 2 * PD_GR)];
+    __shared__ double sbuf[2 * (NTMAX + 2)];
+    const int H = a.src.H, W = a.src.W;
+    const int b = blockIdx.z, part = blockIdx.y, strip = blockIdx.x;
+    const int x0 = strip * a.strip_w;
+    const int x1 = min(W, x0 + a.strip_w);
+    const int xs = max(0, x0 - (PD_GR + 1));
+    const int xe = min(W, x1 + (PD_GR + 1));
+    const int tid = threadIdx.x;
+    const int c = xs + tid;
+    const bool col_active = c < xe;
+    // columns whose smoothed value is needed: the strip plus one neighbour each side
+    const bool do_x = col_active && c >= x0 - 1 && c <= x1;
+    const bool do_nms = col_active && c >= x0 && c < x1;
+    RawPeak* list = a.raw + ((size_t)b * PD_N_PARTS + part) * a.PK;
+    int32_t* count = a.raw_count + b * PD_N_PARTS + part;
+    double* dbg_plane = a.dbg ? a.dbg + ((size_t)b * PD_N_PARTS + part) * (size_t)H * W : nullptr;
+
+    ColLoader<SRC> ld;
+    if (col_active) ld.init(a.src, b, part, c);
+    double win[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) win[i] = 0.0;
+    if (col_active) {
+        // rows 0..11 fill slots 0..11 and, mirrored, rows -1..-12 -> slots 24..13
+#pragma unroll
+        for (int r = 0; r < PD_GR; ++r) {
+            const double v = ld.load(r);
+            win[r] = v;
+            win[24 - r] = v;
+        }
+    }
+    RowState st;
+    st.s_prev1 = 0.0;
+    st.s_prev2 = 0.0;
+    sbuf[tid + 1] = 0.0;
+    sbuf[NTMAX + 2 + tid + 1] = 0.0;
+
+#define PD_STEP(S)                                                                                    \
+    if (y0 + S > H) break;                                                                            \
+    row_step<SRC, S>(a, ld, win, st, ybuf, sbuf, y0 + S, H, W, c, xs, xe, col_active, do_x, do_nms,   \
+                     list, count, dbg_plane);
+    for (int y0 = 0; y0 <= H; y0 += 25) {
+        PD_STEP(0) PD_STEP(1) PD_STEP(2) PD_STEP(3) PD_STEP(4) PD_STEP(5) PD_STEP(6) PD_STEP(7)
+        PD_STEP(8) PD_STEP(9) PD_STEP(10) PD_STEP(11) PD_STEP(12) PD_STEP(13) PD_STEP(14)
+        PD_STEP(15) PD_STEP(16) PD_STEP(17) PD_STEP(18) PD_STEP(19) PD_STEP(20) PD_STEP(21)
+        PD_STEP(22) PD_STEP(23) PD_STEP(24)
+    }
+#undef PD_STEP
+}
+
+// ---------------------------------------------------------------------------------
+// Simple kernels: one thread per pixel, any image size (also images smaller than
+// the filter radius, where the reflection wraps more than once).
+// ---------------------------------------------------------------------------------
+__global__ void k_materialize(MapSource s, int nch, double* out) {
+    // out (B, nch, H, W) float64 = source channel planes
+    const size_t n = (size_t)s.H * s.W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (i >= n) return;
+    const int Y = (int)(i / s.W), X = (int)(i % s.W);
+    double v;
+    if (s.kind == PD_SRC_LOWRES)
+        v = (double)pd_bicubic_at(s.lo + (size_t)b * s.h * s.w * s.C, s.h, s.w, s.C, ch, Y, X, s.ty, s.tx);
+    else
+        v = s.full[((size_t)b * s.Cfull + ch) * n + i];
+    out[((size_t)b * nch + ch) * n + i] = v;
+}
+
+__global__ void k_gauss_axis(const double* in, double* out, int H, int W, int axis, int f32mode) {
+    const size_t n = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = in + (size_t)blockIdx.y * n;
+    const int Y = (int)(i / W), X = (int)(i % W);
+    double t = p[i] * c_gw[12];
+    for (int d = 12; d >= 1; --d) {
+        double lo, hi;
+        if (axis == 0) {
+            lo = p[(size_t)pd_reflect(Y - d, H) * W + X];
+            hi = p[(size_t)pd_reflect(Y + d, H) * W + X];
+        } else {
+            lo = p[(size_t)Y * W + pd_reflect(X - d, W)];
+            hi = p[(size_t)Y * W + pd_reflect(X + d, W)];
+        }
+        t += (lo + hi) * c_gw[12 - d];
+    }
+    out[(size_t)blockIdx.y * n + i] = f32mode ? (double)(float)t : t;
+}
+
+__global__ void k_nms_simple(const double* sm, const double* ori, int H, int W, double thr, RawPeak* raw,
+                             int32_t* raw_count, int PK) {
+    const size_t n = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int plane = blockIdx.y;  // b * 18 + part
+    bool is_peak = false;
+    int Y = 0, X = 0;
+    double score = 0.0;
+    if (i < n) {
+        const double* p = sm + (size_t)plane * n;
+        Y = (int)(i / W);
+        X = (int)(i % W);
+        const double m = p[i];
+        const double up = Y > 0 ? p[i - W] : 0.0;
+        const double down = Y < H - 1 ? p[i + W] : 0.0;
+        const double left = X > 0 ? p[i - 1] : 0.0;
+        const double right = X < W - 1 ? p[i + 1] : 0.0;
+        is_peak = (m >= up) && (m >= down) && (m >= left) && (m >= right) && (m > thr);
+        score = ori[(size_t)plane * n + i];
+    }
+    emit_peak(is_peak, Y, X, score, raw + (size_t)plane * PK, raw_count + plane, PK);
+}
+
+static void pick_strips(int W, int* n_strips, int* strip_w, int* nt) {
+    int best_n = 1, best_w = W, best_nt = 0;
+    double best_eff = -1.0;
+    for (int n = 1; n <= 64; ++n) {
+        const int sw = (W + n - 1) / n;
+        const int cols = n == 1 ? W : sw + 2 * (PD_GR + 1);
+        const int t = ((cols + 63) / 64) * 64;
+        if (t > NTMAX) continue;
+        const double eff = (double)W / ((double)n * t);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best_n = n;
+            best_w = sw;
+            best_nt = t;
+        }
+    }
+    *n_strips = best_n;
+    *strip_w = best_w;
+    *nt = best_nt;
+}
+
+int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
+    const int B = ctx->B, H = ctx->H, W = ctx->W;
+    MapSource src = pd_heat_source(ctx);
+    PD_HIP(ctx, hipMemsetAsync(ctx->raw_count, 0, sizeof(int32_t) * B * PD_N_PARTS, ctx->stream));
+    const int f32mode = (ctx->src_kind == PD_SRC_FULLRES) ? ctx->heat_f32 : 0;
+    // float32 data is thresholded in float32 (numpy compares a float32 array with a
+    // Python float in float32)
+    const double thr = f32mode ? (double)(float)thre1 : thre1;
+    const bool small = H < 2 * PD_GR + 2 || W < 2 * PD_GR + 2;
+    if (ctx->impl == PD_IMPL_FAST && !small) {
+        SmoothArgs a;
+        a.src = src;
+        a.thr = thr;
+        a.f32mode = f32mode;
+        int nt;
+        pick_strips(W, &a.n_strips, &a.strip_w, &nt);
+        if (nt == 0) PD_FAIL(ctx, PD_E_INVALID, "no strip geometry for W=%d", W);
+        a.raw = ctx->raw;
+        a.raw_count = ctx->raw_count;
+        a.PK = ctx->cfg.max_peaks_per_part;
+        a.dbg = dbg_smoothed;
+        dim3 grid(a.n_strips, PD_N_PARTS, B);
+        if (src.kind == PD_SRC_LOWRES)
+            hipLaunchKernelGGL(k_smooth_nms_stream<PD_SRC_LOWRES>, grid, dim3(nt), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(k_smooth_nms_stream<PD_SRC_FULLRES>, grid, dim3(nt), 0, ctx->stream, a);
+        PD_HIP(ctx, hipGetLastError());
+        return PD_OK;
+    }
+    // simple path: materialise the 18 planes, filter axis 0 then axis 1, NMS
+    const size_t n = (size_t)H * W;
+    const size_t need = (size_t)B * PD_N_PARTS * n;
+    if (ctx->tmp_smooth_cap < need) {
+        if (ctx->tmp_smooth) PD_HIP(ctx, hipFree(ctx->tmp_smooth));
+        ctx->tmp_smooth = nullptr;
+        ctx->tmp_smooth_cap = 0;
+        PD_HIP(ctx, hipMalloc(&ctx->tmp_smooth, need * sizeof(double) * 2));
+        ctx->tmp_smooth_cap = need;
+    }
+    if (ctx->tmp_smooth2_cap < need) {
+        if (ctx->tmp_smooth2) PD_HIP(ctx, hipFree(ctx->tmp_smooth2));
+        ctx->tmp_smooth2 = nullptr;
+        ctx->tmp_smooth2_cap = 0;
+        PD_HIP(ctx, hipMalloc(&ctx->tmp_smooth2, need * sizeof(double)));
+        ctx->tmp_smooth2_cap = need;
+    }
+    double* ori = ctx->tmp_smooth;         // (B,18,H,W)
+    double* t0 = ctx->tmp_smooth + need;   // axis-0 result
+    double* t1 = dbg_smoothed ? dbg_smoothed : ctx->tmp_smooth2;
+    const int bs = 256;
+    const unsigned gx = (unsigned)((n + bs - 1) / bs);
+    hipLaunchKernelGGL(k_materialize, dim3(gx, PD_N_PARTS, B), dim3(bs), 0, ctx->stream, src, PD_N_PARTS, ori);
+    hipLaunchKernelGGL(k_gauss_axis, dim3(gx, B * PD_N_PARTS), dim3(bs), 0, ctx->stream, ori, t0, H, W, 0, f32mode);
+    hipLaunchKernelGGL(k_gauss_axis, dim3(gx, B * PD_N_PARTS), dim3(bs), 0, ctx->stream, t0, t1, H, W, 1, f32mode);
+    hipLaunchKernelGGL(k_nms_simple, dim3(gx, B * PD_N_PARTS), dim3(bs), 0, ctx->stream, t1, ori, H, W, thr,
+                       ctx->raw, ctx->raw_count, ctx->cfg.max_peaks_per_part);
+    PD_HIP(ctx, hipGetLastError());
+    return PD_OK;
+}

@@ -1,0 +1,190 @@
+"""Parity of the HIP path (through the C ABI) with the golden vectors of the
+reference's utils/postprocess.py and with the CPU oracle.  Bar: peak coordinates,
+ids, connections and person assignments bit-exact; scores within 1e-5 relative."""
+import numpy as np
+import pytest
+
+from oracle import decode_ref as ref
+from tests import golden_io as gio
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5   # tolerance stated by the task for keypoint scores and PAF integrals
+
+
+@pytest.fixture(scope='module')
+def pp():
+    from poseestimation_amd import postprocess
+    return postprocess
+
+
+@pytest.fixture(scope='module')
+def pdec():
+    from poseestimation_amd import predict_decode
+    return predict_decode
+
+
+def _full(g):
+    heat, paf = gio.scene_inputs(g)
+    return (ref.resize_cubic(heat, fx=8, fy=8).astype(np.float64),
+            ref.resize_cubic(paf, fx=8, fy=8).astype(np.float64))
+
+
+@pytest.mark.parametrize('name', gio.SCENES)
+def test_stage_api_matches_reference_golden(pp, name):
+    """get_peaks / get_connections / multi_person_parse, called one by one as the
+    reference's functions are, against the reference's own outputs."""
+    g = gio.load(name)
+    heat_full, paf_full = _full(g)
+    want_peaks = gio.peaks_from(g['peaks'], g['peaks_part'])
+    peaks = pp.get_peaks(heat_full, 0.1)
+    gio.assert_peaks_equal(peaks, want_peaks, exact_score=True)
+    assert all(isinstance(t[0], np.int64) and isinstance(t[2], np.float64) and isinstance(t[3], int)
+               for pl in peaks for t in pl)
+    conns, special = pp.get_connections(want_peaks, paf_full, 0.05)
+    assert special == list(g['special'])
+    want_conns = gio.conns_from(g['conns'], g['conns_limb'], g['conns_is_list'])
+    gio.assert_conns_equal(conns, want_conns, RTOL)
+    persons = pp.multi_person_parse(want_peaks, want_conns, list(g['special']))
+    gio.assert_persons_equal(persons, g['persons'], RTOL)
+
+
+@pytest.mark.parametrize('name', gio.PEAK_CASES)
+def test_get_peaks_edge_cases(pp, name):
+    g = gio.load('peaks_' + name)
+    hm = (g['heatmap_q'].astype(np.float64) / 16384.0).astype(str(g['dtype']))
+    peaks = pp.get_peaks(hm, float(g['threshold']))
+    gio.assert_peaks_equal(peaks, gio.peaks_from(g['peaks'], g['peaks_part']), exact_score=True)
+    assert all(t[2].dtype == hm.dtype for pl in peaks for t in pl)
+
+
+@pytest.mark.parametrize('idx', gio.CONN_CASES)
+def test_get_connections_cases(pp, idx):
+    g = gio.load('conn_case%d' % idx)
+    paf = (g['paf_q'].astype(np.float64) / 4096.0).astype(str(g['dtype']))
+    peaks = gio.peaks_from(g['peaks'], g['peaks_part'])
+    conns, special = pp.get_connections(peaks, paf, float(g['threshold']))
+    assert special == list(g['special'])
+    gio.assert_conns_equal(conns, gio.conns_from(g['conns'], g['conns_limb'], g['conns_is_list']), RTOL)
+
+
+def test_multi_person_parse_cases(pp):
+    g = gio.load('parse_cases')
+    for i in range(int(g['n'])):
+        pre = '%03d_' % i
+        peaks = gio.peaks_from(g[pre + 'peaks'], g[pre + 'peaks_part'])
+        special = list(g[pre + 'special'])
+        conns = gio.conns_from(g[pre + 'conns'], g[pre + 'conns_limb'])
+        for k in special:
+            conns[k] = []
+        persons = pp.multi_person_parse(peaks, conns, special)
+        gio.assert_persons_equal(persons, g[pre + 'persons'], RTOL)
+
+
+@pytest.mark.parametrize('impl', [0, 1])
+@pytest.mark.parametrize('shape,dtype', [((40, 50), np.float64), ((40, 50), np.float32),
+                                         ((5, 7), np.float64), ((368, 368), np.float64),
+                                         ((100, 700), np.float64), ((64, 1100), np.float32)])
+def test_smoothing_is_bitwise_scipy(shape, dtype, impl):
+    """The Gaussian stage alone against scipy.ndimage.gaussian_filter, bit for bit,
+    for the streaming kernel (impl 0) and the per-pixel kernels (impl 1)."""
+    from scipy.ndimage import gaussian_filter
+    from poseestimation_amd import _ffi
+    H, W = shape
+    x = np.random.RandomState(5).randn(H, W, 18).astype(dtype)
+    with _ffi.Context(max_batch=1, max_h=H, max_w=W) as ctx:
+        ctx.set_impl(impl)
+        ctx.load_fullres(np.ascontiguousarray(x[None]), None, 1, H, W)
+        sm = ctx.debug_smoothed(1, H, W)[0]
+    for c in range(18):
+        want = gaussian_filter(x[:, :, c], sigma=3).astype(np.float64)
+        np.testing.assert_array_equal(sm[c], want)
+
+
+@pytest.mark.parametrize('name', gio.SCENES)
+@pytest.mark.parametrize('impl', [0, 1])
+def test_fused_batch_mode_p_matches_reference_golden(pdec, name, impl):
+    """Network outputs in, skeletons out, in one call: the fused path (bicubic on
+    the fly, nothing materialised) against the reference's outputs."""
+    g = gio.load(name)
+    heat, paf = gio.scene_inputs(g)
+    H, W = int(g['H']), int(g['W'])
+    eng = pdec.DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='P', max_peaks_per_part=128,
+                            max_persons=128, max_pairs_per_image=40000)
+    eng.ctx.set_impl(impl)
+    res = eng.decode_batch(np.stack([heat, heat]), np.stack([paf, paf]))
+    for b in range(2):
+        gio.assert_peaks_equal(res.all_peaks(b), gio.peaks_from(g['peaks'], g['peaks_part']), exact_score=True)
+        conns, special = res.connections(b)
+        assert special == list(g['special'])
+        gio.assert_conns_equal(conns, gio.conns_from(g['conns'], g['conns_limb'], g['conns_is_list']), RTOL)
+        gio.assert_persons_equal(res.subset(b), g['persons'], RTOL)
+    eng.close()
+
+
+@pytest.mark.parametrize('seed,P,H,W', [(21, 4, 368, 368), (22, 6, 200, 312), (23, 1, 96, 96)])
+def test_fused_batch_mode_d_matches_oracle(pdec, seed, P, H, W):
+    from poseestimation_amd import synth
+    heat, paf = synth.scene(H, W, P, seed, paf_order='xy')
+    eng = pdec.DecodeEngine(max_batch=1, max_h=H, max_w=W, mode='D')
+    res = eng.decode_batch(heat[None], paf[None], out_hw=(H, W))
+    hf = ref.resize_cubic(heat, fx=8, fy=8)[:H, :W].astype(np.float64)
+    pf = ref.resize_cubic(paf, fx=8, fy=8)[:H, :W].astype(np.float64)
+    cand, peaks, subset = ref.decode(hf, pf, 0.1, 0.05, 'D')
+    g_cand, g_peaks, g_subset = res.image(0)
+    gio.assert_peaks_equal(g_peaks, peaks, exact_score=True)
+    np.testing.assert_array_equal(g_cand, cand)
+    conns, special = ref.get_connections(peaks, pf, 0.05, 'D')
+    g_conns, g_special = res.connections(0)
+    assert g_special == special
+    gio.assert_conns_equal(g_conns, conns, RTOL)
+    gio.assert_persons_equal(g_subset, subset, RTOL)
+    eng.close()
+
+
+@pytest.mark.parametrize('hs,ws,crop,out', [(23, 23, (184, 184), (368, 368)), (46, 46, (368, 368), (368, 368)),
+                                            (69, 69, (552, 552), (368, 368)), (47, 62, (368, 491), (480, 640)),
+                                            (12, 9, (90, 70), (45, 35))])
+def test_resize_matches_oracle_bitwise(pdec, hs, ws, crop, out):
+    """x8 bicubic + crop + second resize (predict.py:63-65) for one scale."""
+    rng = np.random.RandomState(9)
+    heat = rng.randn(1, hs, ws, 19).astype(np.float32)
+    paf = rng.randn(1, hs, ws, 38).astype(np.float32)
+    pads = [(8 * hs - crop[0], 8 * ws - crop[1])]
+    want_h, want_p = ref.upsample_average([heat[0]], [paf[0]], pads, out)
+    eng = pdec.DecodeEngine(1, out[0], out[1], mode='D', max_peaks_per_part=16, max_pairs_per_image=16,
+                            max_persons=16)
+    eng.upsample_average([heat], [paf], pads, out)
+    got_h, got_p = eng.ctx.read_fullres(1, out[0], out[1])
+    np.testing.assert_array_equal(got_h[0], want_h)
+    np.testing.assert_array_equal(got_p[0], want_p)
+    eng.close()
+
+
+def test_multiscale_average_and_decode(pdec):
+    """predict.py:49-72 with the four test scales, then the mode-D decode."""
+    from poseestimation_amd import synth
+    H = W = 184
+    scales = [0.5, 1.0, 1.5, 2.0]
+    outs = [synth.scene(H, W, 2, 31, paf_order='xy', scale=s) for s in scales]
+    heats = [o[0] for o in outs]
+    pafs = [o[1] for o in outs]
+    pads = []
+    for s, hm in zip(scales, heats):
+        sh = int(round(H * s))
+        pads.append(((8 - sh % 8) % 8, (8 - sh % 8) % 8))
+        assert hm.shape[0] * 8 - pads[-1][0] == sh
+    want_h, want_p = ref.upsample_average(heats, pafs, pads, (H, W))
+    got_h, got_p = pdec.upsample_average(list(zip(heats, pafs)), pads, (H, W))
+    np.testing.assert_array_equal(got_h, want_h)
+    np.testing.assert_array_equal(got_p, want_p)
+    cand, peaks, subset = ref.decode(want_h, want_p, 0.1, 0.05, 'D')
+    g_cand, g_peaks, g_subset = pdec.decode(got_h, got_p)
+    gio.assert_peaks_equal(g_peaks, peaks, exact_score=True)
+    np.testing.assert_array_equal(g_cand, cand)
+    gio.assert_persons_equal(g_subset, subset, RTOL)
+    eng = pdec.DecodeEngine(1, H, W, mode='D')
+    res = eng.decode_multiscale([h[None] for h in heats], [p[None] for p in pafs], pads, (H, W))
+    np.testing.assert_array_equal(res.candidate(0), cand)
+    gio.assert_persons_equal(res.subset(0), subset, RTOL)
+    eng.close()
