@@ -26,6 +26,7 @@ struct PairArgs {
     int PK;
     int max_pairs;
     double* pair_score;
+    int32_t* status;
 };
 
 // Two adjacent channels (ch, ch+1) of a (h, w, C) float32 map, bicubic at (Y, X);
@@ -64,6 +65,10 @@ k_pair_scores(PairArgs a) {
     if (tid < PD_N_PARTS) s_cnt[tid] = a.part_count[b * PD_N_PARTS + tid];
     __syncthreads();
     const int total = s_off[PD_N_LIMBS];
+    if (total < 0) {  // more candidate pairs than the context was sized for
+        if (tid == 0 && blockIdx.x == 0) a.status[b] = PD_E_OVERFLOW;
+        return;
+    }
     const int group = tid >> 4;
     const int i = tid & 15;
     const int lane = tid & 63;
@@ -192,6 +197,10 @@ k_match(MatchArgs a) {
     int32_t* out_count = a.limb_count + b * PD_N_LIMBS + k;
     if (nA == 0 || nB == 0) {  // utils/postprocess.py:92-95
         if (lane == 0) *out_count = -1;
+        return;
+    }
+    if (a.pair_off[b * (PD_N_LIMBS + 1) + PD_N_LIMBS] < 0) {  // pair capacity exceeded, image flagged
+        if (lane == 0) *out_count = 0;
         return;
     }
     const int off = a.pair_off[b * (PD_N_LIMBS + 1) + k];
@@ -343,6 +352,7 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     a.PK = ctx->cfg.max_peaks_per_part;
     a.max_pairs = ctx->cfg.max_pairs_per_image;
     a.pair_score = ctx->pair_score;
+    a.status = ctx->status;
     int per_image = (ctx->cfg.max_pairs_per_image + 15) / 16;
     if (per_image > 64) per_image = 64;
     hipLaunchKernelGGL(k_pair_scores, dim3(per_image, ctx->B), dim3(256), 0, ctx->stream, a);

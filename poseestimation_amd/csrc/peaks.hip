@@ -33,16 +33,19 @@ k_sort_peaks(const RawPeak* __restrict__ raw, const int32_t* __restrict__ raw_co
             acc += s_cnt[p];
         }
         s_base[PD_N_PARTS] = acc;
+        // candidate-pair ranges per limb; a total of -1 tells the connection stage
+        // that max_pairs_per_image is too small (not an error for peaks alone)
         long long pairs = 0;
+        bool pairs_over = false;
         for (int k = 0; k < PD_N_LIMBS; ++k) {
             pair_off[b * (PD_N_LIMBS + 1) + k] = (int32_t)pairs;
             pairs += (long long)s_cnt[pd_limb_from(k)] * s_cnt[pd_limb_to(k)];
             if (pairs > max_pairs) {
                 pairs = max_pairs;
-                s_over = 1;
+                pairs_over = true;
             }
         }
-        pair_off[b * (PD_N_LIMBS + 1) + PD_N_LIMBS] = (int32_t)pairs;
+        pair_off[b * (PD_N_LIMBS + 1) + PD_N_LIMBS] = pairs_over ? -1 : (int32_t)pairs;
     }
     __syncthreads();
     if (tid < PD_N_PARTS) part_count[b * PD_N_PARTS + tid] = s_cnt[tid];
