@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Decode throughput benchmark: network outputs (19 heatmaps + 38 PAFs at stride 8) in
+HBM -> per-person skeletons on the host, on 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" decodes one batch of synthetic network outputs per GPU (weak scaling: the
+per-GPU batch is fixed).  For N > 1 launch under torch.distributed.run; each rank owns
+one GPU and one HIP stream, images are sharded with no data-path collective and the
+skeleton lists are gathered to rank 0 (one RCCL gather per step).  Rank 0 prints one
+JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (batch per GPU, H, W, people per image, description)
+    'b64_368': (64, 368, 368, (1, 8), 'synthetic batch 64 at 368x368 (46x46x57 network output), single scale'),
+    'b256_656': (256, 656, 656, 30, 'synthetic batch 256 at 656x656, ~30 people per image'),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='b64_368', choices=sorted(WORKLOADS))
+    ap.add_argument('--mode', default='D', choices=['P', 'D'])
+    ap.add_argument('--cpu-images', type=int, default=12, help='images timed on the CPU oracle (rank 0, N=1)')
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from poseestimation_amd import _ffi, sharding, synth
+    from poseestimation_amd.predict_decode import DecodeEngine, Results
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    B, H, W, people, desc = WORKLOADS[args.workload]
+    h, w = H // 8, W // 8
+    heat, paf = synth.batch(B, H, W, people, seed0=rank * B, paf_order='xy' if args.mode == 'D' else 'yx')
+    d_heat = torch.from_numpy(heat).cuda()
+    d_paf = torch.from_numpy(paf).cuda()
+    torch.cuda.synchronize()
+
+    eng = DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=local_rank,
+                       max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000)
+    gather_cap = 1 << 20
+    while gather_cap < B * 16384:
+        gather_cap <<= 1
+
+    def step():
+        eng.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
+        res = eng.ctx.fetch()            # waits for the stream, copies the packed skeletons to the host
+        if world > 1:
+            return sharding.gather_results(res, gather_cap)
+        return res
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        last = step()
+    eng.ctx.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.ctx.profile_read()
+    eng.ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        images = world * B * args.steps
+        n, N = h * w, H * W
+        # dominant kernel: Gaussian + NMS over the 18 part channels, fed by the x8
+        # bicubic upsample evaluated on the fly.  Algorithmic bytes per image of that
+        # kernel's share: upsample read 18*n*4 + write 18*N*4, Gaussian read + write
+        # 2*18*N*4, NMS read 18*N*4  =  72*n + 288*N.
+        sm_ms, sm_n = prof['smooth_nms']
+        alg_bytes = B * (72.0 * n + 288.0 * N)
+        avg_s = (sm_ms / max(sm_n, 1)) * 1e-3
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.workload)
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                traffic = json.load(f).get('smooth_nms_hbm_bytes_per_launch')
+        # the whole decode against the whole-path byte count per image:
+        # 228*n + 228*N + 216*N (+ 80 bytes per candidate pair, not counted here)
+        job_bytes = 228.0 * n + 444.0 * N
+        value = images / dt
+        out = {
+            'metric': 'decoded images/sec (heatmap+PAF->skeletons) at %dx%d' % (H, W),
+            'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': desc, 'batch_per_gpu': B, 'mode': args.mode,
+                       'people_per_image': list(people) if isinstance(people, tuple) else people,
+                       'outputs': 'packed skeleton lists copied to the host every step'},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_smooth_nms_stream', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': sm_n,
+                         'algorithmic_bytes_per_launch': alg_bytes},
+            'job_hbm_frac_per_gpu': (value / world) * job_bytes / 1e9 / HBM_PEAK_GBS,
+            'stage_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+        }
+        res0 = last
+        out['persons_last_step'] = int(res0['person_count'].sum())
+
+        if world == 1 and not args.no_cpu:
+            from oracle import decode_ref as ref
+            ncpu = min(args.cpu_images, B)
+            r = Results(res0, eng.mode)
+            tc = time.perf_counter()
+            ok = True
+            for b in range(ncpu):
+                hf = ref.resize_cubic(heat[b], fx=8, fy=8).astype(np.float64)
+                pf = ref.resize_cubic(paf[b], fx=8, fy=8).astype(np.float64)
+                peaks = ref.get_peaks(hf, 0.1, args.mode, use_scipy=True)
+                conns, special = ref.get_connections(peaks, pf, 0.05, args.mode)
+                subset = ref.multi_person_parse(peaks, conns, special, args.mode)
+                g = r.subset(b)
+                ok = ok and g.shape == subset.shape and np.array_equal(g[:, :18], subset[:, :18]) \
+                    and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0)
+            tcpu = time.perf_counter() - tc
+            out['cpu_baseline'] = {'value': ncpu / tcpu, 'unit': 'images/s', 'cores': 1, 'kind': 'port',
+                                   'sample': 'first %d images of the same batch through oracle/decode_ref.py '
+                                             '(numpy bicubic + scipy gaussian_filter + numpy decode), one thread; '
+                                             'host has %d cpus' % (ncpu, os.cpu_count())}
+            out['parity_checked_images'] = ncpu
+            out['parity_ok'] = bool(ok)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

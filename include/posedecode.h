@@ -156,6 +156,30 @@ int pd_sync_totals(pd_ctx* ctx, pd_totals* totals);
 int pd_fetch(pd_ctx* ctx, int32_t* part_count, int32_t* limb_count, int32_t* person_count,
              int32_t* status, pd_peak* peaks, pd_conn* conns, double* persons);
 
+/* Device addresses of the packed results and count tables (valid after
+ * pd_sync_totals until the next stage call on this context), for callers that
+ * forward them without a host round trip (e.g. a collective gather).  Any output
+ * pointer may be NULL. */
+int pd_packed_device(pd_ctx* ctx, void** peaks, void** conns, void** persons, void** part_count,
+                     void** limb_count, void** person_count);
+
+/* Per-stage timing with HIP events recorded on the context's stream around every
+ * kernel launch of a stage.  pd_profile(ctx, 1) starts collecting;
+ * pd_profile_read waits for the stream and returns, per stage, the summed
+ * milliseconds and the number of launches since the last read. */
+enum {
+    PD_STAGE_RESIZE = 0,     /* bicubic resize / average / layout kernels */
+    PD_STAGE_SMOOTH_NMS = 1, /* Gaussian + NMS + peak emission */
+    PD_STAGE_SORT = 2,       /* peak ordering and id assignment */
+    PD_STAGE_PAIRS = 3,      /* PAF line integrals */
+    PD_STAGE_MATCH = 4,      /* per-limb sort + greedy matching */
+    PD_STAGE_PARSE = 5,      /* person assembly */
+    PD_STAGE_PACK = 6,       /* result packing */
+    PD_N_STAGES = 7
+};
+int pd_profile(pd_ctx* ctx, int enable);
+int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);
+
 /* The smoothed heatmap the peak stage compares (scipy.ndimage.gaussian_filter,
  * sigma = 3), (B, 18, H, W) float64; test hook for the filter alone. */
 int pd_debug_smoothed(pd_ctx* ctx, double* out);

@@ -21,7 +21,9 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read']
+
+STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack']
 
 
 class Config(C.Structure):
@@ -83,6 +85,9 @@ def lib():
     L.pd_sync_totals.argtypes = [vp, C.POINTER(Totals)]
     L.pd_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.pd_debug_smoothed.argtypes = [vp, vp]
+    L.pd_packed_device.argtypes = [vp] + [C.POINTER(vp)] * 6
+    L.pd_profile.argtypes = [vp, i32]
+    L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ('pd_last_error', 'pd_version', 'pd_stream'):
@@ -235,6 +240,23 @@ class Context:
                                    _ptr(out['person_count']), _ptr(out['status']), _ptr(out['peaks']),
                                    _ptr(out['conns']), _ptr(out['persons'])))
         return out
+
+    def profile(self, enable=True):
+        self.check(self.L.pd_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """{stage: (total_ms, launches)} since the last read (waits for the stream)."""
+        ms = (C.c_double * len(STAGES))()
+        n = (C.c_int64 * len(STAGES))()
+        self.check(self.L.pd_profile_read(self._h, ms, n))
+        return {s: (ms[i], n[i]) for i, s in enumerate(STAGES)}
+
+    def packed_device(self):
+        """Device addresses of the packed results: peaks, conns, persons, part_count,
+        limb_count, person_count."""
+        ptrs = [C.c_void_p() for _ in range(6)]
+        self.check(self.L.pd_packed_device(self._h, *[C.byref(p) for p in ptrs]))
+        return [p.value for p in ptrs]
 
     def debug_smoothed(self, B, H, W):
         out = np.empty((B, 18, H, W), np.float64)

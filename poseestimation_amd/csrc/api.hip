@@ -113,8 +113,8 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
 
 extern "C" int pd_destroy(pd_ctx* ctx) {
     PD_CHECK_CTX(ctx);
-    hipSetDevice(ctx->cfg.device_id);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->cfg.device_id);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void* ptrs[] = {ctx->stage_heat, ctx->stage_paf, ctx->full_heat, ctx->full_paf, ctx->tmp_up, ctx->tmp_in,
                     ctx->tmp_smooth, ctx->tmp_smooth2, ctx->tabs[0].i, ctx->tabs[0].f, ctx->tabs[1].i,
                     ctx->tabs[1].f, ctx->tabs[2].i, ctx->tabs[2].f, ctx->raw, ctx->raw_count, ctx->pk_y,
@@ -123,9 +123,12 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->person_count, ctx->status, ctx->pack_off, ctx->packed_peaks, ctx->packed_conns,
                     ctx->packed_persons};
     for (void* p : ptrs)
-        if (p) hipFree(p);
-    if (ctx->host_totals) hipHostFree(ctx->host_totals);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+        if (p) (void)hipFree(p);
+    if (ctx->host_totals) (void)hipHostFree(ctx->host_totals);
+    for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+    free(ctx->prof_ev);
+    free(ctx->prof_stage);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PD_OK;
 }
@@ -385,7 +388,7 @@ extern "C" int pd_debug_smoothed(pd_ctx* ctx, double* out) {
             rc = PD_E_HIP;
         }
     }
-    hipFree(dev);
+    (void)hipFree(dev);
     return rc;
 }
 
@@ -530,6 +533,67 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     int rc = pd_set_lowres(ctx, heat, paf, B, h, w, H, W, mem);
     if (rc != PD_OK) return rc;
     return pd_decode_fullres(ctx, thre1, thre2);
+}
+
+void pd_prof_begin(pd_ctx* ctx, int stage) {
+    if (!ctx->prof_on) return;
+    if (ctx->prof_n == ctx->prof_cap) {
+        const int ncap = ctx->prof_cap ? ctx->prof_cap * 2 : 256;
+        hipEvent_t* ev = (hipEvent_t*)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * ncap);
+        int* st = (int*)realloc(ctx->prof_stage, sizeof(int) * ncap);
+        if (ev) ctx->prof_ev = ev;
+        if (st) ctx->prof_stage = st;
+        if (!ev || !st) return;
+        for (int i = 2 * ctx->prof_cap; i < 2 * ncap; ++i)
+            if (hipEventCreate(&ctx->prof_ev[i]) != hipSuccess) return;
+        ctx->prof_cap = ncap;
+    }
+    ctx->prof_stage[ctx->prof_n] = stage;
+    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], ctx->stream);
+}
+
+void pd_prof_end(pd_ctx* ctx) {
+    if (!ctx->prof_on || ctx->prof_n >= ctx->prof_cap) return;
+    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream);
+    ++ctx->prof_n;
+}
+
+extern "C" int pd_profile(pd_ctx* ctx, int enable) {
+    PD_CHECK_CTX(ctx);
+    ctx->prof_on = enable != 0;
+    return PD_OK;
+}
+
+extern "C" int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < PD_N_STAGES; ++s) {
+        if (ms) ms[s] = 0.0;
+        if (launches) launches[s] = 0;
+    }
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        float t = 0.f;
+        PD_HIP(ctx, hipEventElapsedTime(&t, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        const int s = ctx->prof_stage[i];
+        if (ms) ms[s] += (double)t;
+        if (launches) launches[s] += 1;
+    }
+    ctx->prof_n = 0;
+    return PD_OK;
+}
+
+extern "C" int pd_packed_device(pd_ctx* ctx, void** peaks, void** conns, void** persons, void** part_count,
+                                void** limb_count, void** person_count) {
+    PD_CHECK_CTX(ctx);
+    if (!ctx->packed) PD_FAIL(ctx, PD_E_STATE, "pd_packed_device: call pd_pack (or a decode entry point) first");
+    if (peaks) *peaks = ctx->packed_peaks;
+    if (conns) *conns = ctx->packed_conns;
+    if (persons) *persons = ctx->packed_persons;
+    if (part_count) *part_count = ctx->part_count;
+    if (limb_count) *limb_count = ctx->limb_count;
+    if (person_count) *person_count = ctx->person_count;
+    return PD_OK;
 }
 
 extern "C" int pd_sync_totals(pd_ctx* ctx, pd_totals* totals) {

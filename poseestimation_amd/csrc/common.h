@@ -115,7 +115,15 @@ struct pd_ctx {
     double* packed_persons;
     int64_t* host_totals;  // pinned: [3] totals + first_bad
     int have_peaks, have_conns, have_persons, packed;
+    // ---- stage timing (pd_profile) ----
+    int prof_on, prof_n, prof_cap;
+    hipEvent_t* prof_ev;  // [2*i] start, [2*i+1] stop
+    int* prof_stage;
 };
+
+// Record a start / stop event pair around a stage's kernel launch when profiling is on.
+void pd_prof_begin(pd_ctx* ctx, int stage);
+void pd_prof_end(pd_ctx* ctx);
 
 #define PD_FAIL(ctx, code, ...)                                  \
     do {                                                         \

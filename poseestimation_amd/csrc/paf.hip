@@ -355,7 +355,9 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     a.status = ctx->status;
     int per_image = (ctx->cfg.max_pairs_per_image + 15) / 16;
     if (per_image > 64) per_image = 64;
+    pd_prof_begin(ctx, PD_STAGE_PAIRS);
     hipLaunchKernelGGL(k_pair_scores, dim3(per_image, ctx->B), dim3(256), 0, ctx->stream, a);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }
@@ -377,7 +379,9 @@ int pd_launch_match(pd_ctx* ctx) {
     a.conn_conf = ctx->conn_conf;
     a.limb_count = ctx->limb_count;
     const size_t lds = (size_t)a.cap * 12 + 2 * (size_t)a.PK;
+    pd_prof_begin(ctx, PD_STAGE_MATCH);
     hipLaunchKernelGGL(k_match, dim3(PD_N_LIMBS, ctx->B), dim3(64), lds, ctx->stream, a);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }

@@ -231,7 +231,9 @@ int pd_launch_parse(pd_ctx* ctx) {
     a.person_count = ctx->person_count;
     a.status = ctx->status;
     const size_t lds = (size_t)a.max_persons * 20 * sizeof(double);
+    pd_prof_begin(ctx, PD_STAGE_PARSE);
     hipLaunchKernelGGL(k_parse, dim3(ctx->B), dim3(64), lds, ctx->stream, a);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }
@@ -259,8 +261,10 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.out_conns = ctx->packed_conns;
     a.out_persons = ctx->packed_persons;
     a.totals = ctx->pack_off + 3 * ((size_t)ctx->cfg.max_batch + 1);
+    pd_prof_begin(ctx, PD_STAGE_PACK);
     hipLaunchKernelGGL(k_pack_offsets, dim3(1), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(128), 0, ctx->stream, a);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }

@@ -72,9 +72,11 @@ k_sort_peaks(const RawPeak* __restrict__ raw, const int32_t* __restrict__ raw_co
 }
 
 int pd_launch_sort_peaks(pd_ctx* ctx) {
+    pd_prof_begin(ctx, PD_STAGE_SORT);
     hipLaunchKernelGGL(k_sort_peaks, dim3(ctx->B), dim3(256), 0, ctx->stream, ctx->raw, ctx->raw_count,
                        ctx->cfg.max_peaks_per_part, ctx->W, ctx->cfg.max_pairs_per_image, ctx->pk_y, ctx->pk_x,
                        ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off, ctx->status);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }

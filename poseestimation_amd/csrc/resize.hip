@@ -157,8 +157,10 @@ int pd_launch_resize_up8(pd_ctx* ctx, const float* src, int C, int B, int hs, in
     if (rc != PD_OK) return rc;
     const CubicTable ty = ctx->tabs[1].ty, tx = ctx->tabs[1].tx;
     const size_t n = (size_t)Hd * Wd;
+    pd_prof_begin(ctx, PD_STAGE_RESIZE);
     hipLaunchKernelGGL(k_resize_up, dim3((unsigned)((n + 255) / 256), C, B), dim3(256), 0, ctx->stream, src, C,
                        hs, ws, ty, tx, dst, Hd, Wd);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }
@@ -174,8 +176,10 @@ int pd_launch_resize_accum(pd_ctx* ctx, const float* up, int C, int B, int Hs, i
         tx = ctx->tabs[2].tx;
     }
     const size_t n = (size_t)H * W;
+    pd_prof_begin(ctx, PD_STAGE_RESIZE);
     hipLaunchKernelGGL(k_resize_accum, dim3((unsigned)((n + 255) / 256), C, B), dim3(256), 0, ctx->stream, up, C,
                        Hs, Ws, crop_h, crop_w, ty, tx, identity, dst, H, W, n_scales, first);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }
@@ -184,16 +188,20 @@ int pd_launch_hwc_to_planar(pd_ctx* ctx, const void* src, int dtype, int Csrc, i
                             int W, double* dst) {
     const size_t n = (size_t)H * W;
     const int nch = Csrc < Cdst ? Csrc : Cdst;
+    pd_prof_begin(ctx, PD_STAGE_RESIZE);
     hipLaunchKernelGGL(k_hwc_to_planar, dim3((unsigned)((n + 255) / 256), nch, B), dim3(256), 0, ctx->stream, src,
                        dtype, Csrc, Cdst, H, W, dst);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }
 
 int pd_launch_planar_to_hwc(pd_ctx* ctx, const double* src, int C, int B, int H, int W, double* dst) {
     const size_t n = (size_t)H * W * C;
+    pd_prof_begin(ctx, PD_STAGE_RESIZE);
     hipLaunchKernelGGL(k_planar_to_hwc, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, ctx->stream, src, C, H,
                        W, dst);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }

@@ -349,10 +349,12 @@ int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
         a.PK = ctx->cfg.max_peaks_per_part;
         a.dbg = dbg_smoothed;
         dim3 grid(a.n_strips, PD_N_PARTS, B);
+        pd_prof_begin(ctx, PD_STAGE_SMOOTH_NMS);
         if (src.kind == PD_SRC_LOWRES)
             hipLaunchKernelGGL(k_smooth_nms_stream<PD_SRC_LOWRES>, grid, dim3(nt), 0, ctx->stream, a);
         else
             hipLaunchKernelGGL(k_smooth_nms_stream<PD_SRC_FULLRES>, grid, dim3(nt), 0, ctx->stream, a);
+        pd_prof_end(ctx);
         PD_HIP(ctx, hipGetLastError());
         return PD_OK;
     }
@@ -378,11 +380,13 @@ int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
     double* t1 = dbg_smoothed ? dbg_smoothed : ctx->tmp_smooth2;
     const int bs = 256;
     const unsigned gx = (unsigned)((n + bs - 1) / bs);
+    pd_prof_begin(ctx, PD_STAGE_SMOOTH_NMS);
     hipLaunchKernelGGL(k_materialize, dim3(gx, PD_N_PARTS, B), dim3(bs), 0, ctx->stream, src, PD_N_PARTS, ori);
     hipLaunchKernelGGL(k_gauss_axis, dim3(gx, B * PD_N_PARTS), dim3(bs), 0, ctx->stream, ori, t0, H, W, 0, f32mode);
     hipLaunchKernelGGL(k_gauss_axis, dim3(gx, B * PD_N_PARTS), dim3(bs), 0, ctx->stream, t0, t1, H, W, 1, f32mode);
     hipLaunchKernelGGL(k_nms_simple, dim3(gx, B * PD_N_PARTS), dim3(bs), 0, ctx->stream, t1, ori, H, W, thr,
                        ctx->raw, ctx->raw_count, ctx->cfg.max_peaks_per_part);
+    pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
 }
