@@ -1,0 +1,191 @@
+"""CPU-side tests: the C-ABI library loads and exports what include/posedecode.h
+declares (no compute without a GPU), the host logic, the result blobs and the
+world_size-2 gather over gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, 'include', 'posedecode.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(pd_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from poseestimation_amd import _ffi
+    lib = _ffi.lib()
+    declared = _header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), 'libposedecode.so does not export %s' % name
+    assert sorted(_ffi.EXPORTS) == declared
+    assert b'gfx950' in lib.pd_version()
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible')
+    from poseestimation_amd import _ffi
+    with pytest.raises(RuntimeError):
+        _ffi.Context(max_batch=1, max_h=64, max_w=64)
+    from poseestimation_amd import postprocess
+    with pytest.raises(RuntimeError):
+        postprocess.get_peaks(np.zeros((40, 40, 18)), 0.1)
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, 'poseestimation_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'oracle' not in src.replace('oracle/decode_ref.py', ''), fn
+
+
+def test_config_tables_match_reference_values():
+    from poseestimation_amd import config
+    assert config.limb_seq[0] == [1, 8] and config.limb_seq[18] == [15, 17]
+    assert config.map_idx[7] == [14, 15]
+    assert len(config.limb_seq) == 19 and len(config.coco_to_ours) == 17
+    from oracle import decode_ref as ref
+    assert tuple(ref.LIMB_FROM) == tuple(config.LIMB_FROM) and tuple(ref.LIMB_TO) == tuple(config.LIMB_TO)
+
+
+def test_pad_right_down_corner():
+    from poseestimation_amd.predict_decode import pad_right_down_corner
+    img = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    out, pad = pad_right_down_corner(img, 8, 128)
+    assert pad == [0, 0, 3, 1] and out.shape == (8, 8, 3)
+    assert np.array_equal(out[:5, :7], img) and np.all(out[5:] == 128) and np.all(out[:, 7:] == 128)
+    out, pad = pad_right_down_corner(np.zeros((16, 8, 3), np.uint8), 8, 128)
+    assert pad == [0, 0, 0, 0] and out.shape == (16, 8, 3)
+
+
+def test_helpers_is_isolated_and_id_to_idx():
+    from poseestimation_amd.postprocess import _id_to_idx, is_isolated
+    a = -np.ones(18); b = -np.ones(18)
+    a[3] = 5; b[4] = 6
+    assert is_isolated(a, b)
+    b[3] = 0
+    assert not is_isolated(a, b)
+    peaks = [(1, 2, 0.5, 10), (3, 4, 0.6, 11), (5, 6, 0.7, 11)]
+    assert _id_to_idx(peaks, 10) == 0 and _id_to_idx(peaks, 11) == 2
+    with pytest.raises(UnboundLocalError):
+        _id_to_idx(peaks, 99)
+
+
+def test_shard_range_covers_batch_in_order():
+    from poseestimation_amd.sharding import shard_range
+    for n in (1, 7, 64, 128, 1000, 1024):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert max(hi - lo for lo, hi in spans) == -(-n // world)
+
+
+def _fake_results(B, seed):
+    from poseestimation_amd._ffi import CONN_DTYPE, PEAK_DTYPE
+    rng = np.random.RandomState(seed)
+    part = rng.randint(0, 4, (B, 18)).astype(np.int32)
+    limb = rng.randint(-1, 3, (B, 19)).astype(np.int32)
+    pers = rng.randint(0, 3, (B,)).astype(np.int32)
+    pk = np.zeros(int(part.sum()), PEAK_DTYPE)
+    pk['y'] = rng.randint(0, 368, len(pk)); pk['x'] = rng.randint(0, 368, len(pk)); pk['score'] = rng.rand(len(pk))
+    cn = np.zeros(int(np.maximum(limb, 0).sum()), CONN_DTYPE)
+    cn['id_a'] = rng.randint(0, 50, len(cn)); cn['score'] = rng.rand(len(cn))
+    return {'B': B, 'part_count': part, 'limb_count': limb, 'person_count': pers,
+            'status': np.zeros(B, np.int32), 'peaks': pk, 'conns': cn,
+            'persons': rng.rand(int(pers.sum()), 20)}
+
+
+def test_result_blob_round_trip_and_concat():
+    from poseestimation_amd import sharding
+    r0, r1 = _fake_results(5, 1), _fake_results(3, 2)
+    b0 = sharding.pack_blob(r0)
+    assert sharding.blob_nbytes(np.concatenate([b0, np.zeros(100, np.uint8)])) == b0.size
+    u0 = sharding.unpack_blob(b0)
+    for k in r0:
+        assert np.array_equal(u0[k], r0[k]), k
+    merged = sharding.concat_results([u0, sharding.unpack_blob(sharding.pack_blob(r1))])
+    assert merged['B'] == 8 and len(merged['peaks']) == len(r0['peaks']) + len(r1['peaks'])
+    assert np.array_equal(merged['part_count'][5:], r1['part_count'])
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from poseestimation_amd import sharding
+from tests.test_host import _fake_results
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+lo, hi = sharding.shard_range(9, 2, rank)
+res = _fake_results(hi - lo, 40 + rank)
+out = sharding.gather_results(res, 1 << 16)
+if rank == 0:
+    want = sharding.concat_results([_fake_results(5, 40), _fake_results(4, 41)])
+    assert out['B'] == 9
+    for k in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
+        assert np.array_equal(out[k], want[k]), k
+    print('GATHER_OK')
+else:
+    assert out is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gather_world_size_2_gloo(tmp_path):
+    """The N > 1 path: two ranks decode their contiguous blocks (results faked on
+    CPU), one fixed-size gather to rank 0 restores image order."""
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % {'root': ROOT, 'port': port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'GATHER_OK' in outs[0]
+
+
+def test_synth_is_deterministic_and_shaped():
+    from poseestimation_amd import synth
+    h1, p1 = synth.scene(368, 368, 3, 7)
+    h2, p2 = synth.scene(368, 368, 3, 7)
+    assert h1.shape == (46, 46, 19) and p1.shape == (46, 46, 38) and h1.dtype == np.float32
+    assert np.array_equal(h1, h2) and np.array_equal(p1, p2)
+    hb, pb = synth.batch(3, 184, 248, (1, 4), seed0=5)
+    assert hb.shape == (3, 23, 31, 19) and pb.shape == (3, 23, 31, 38)
+
+
+def test_coco_records_match_oracle_restatement():
+    """evaluate.py:44-74 (host-side consumer of the decode)."""
+    from oracle import decode_ref as ref
+    from poseestimation_amd import coco, config
+    rng = np.random.RandomState(3)
+    cand = np.concatenate([rng.randint(0, 368, (40, 2)).astype(float), rng.rand(40, 1),
+                           np.arange(40.)[:, None]], axis=1)
+    subset = -np.ones((4, 20))
+    for p in range(4):
+        idx = rng.permutation(18)[:rng.randint(4, 18)]
+        subset[p, idx] = rng.randint(0, 40, len(idx))
+        subset[p, 18] = rng.rand() * 20
+        subset[p, 19] = len(idx)
+    got = coco.coco_records(cand, subset, 42)
+    want = ref.coco_records(cand, subset, 42, config.coco_to_ours)
+    assert len(got) == len(want) == 4
+    for g, w in zip(got, want):
+        assert g['image_id'] == 42 and g['category_id'] == 1 and g['score'] == w['score']
+        assert [float(v) for v in g['keypoints']] == [float(v) for v in w['keypoints']]
+    assert coco.coco_records(np.zeros((0, 4)), np.zeros((0, 20)), 1) == []
