@@ -42,8 +42,11 @@ enum { PD_MODE_P = 0, /* utils/postprocess.py semantics */
        PD_MODE_D = 1  /* predict.py detect() semantics */ };
 enum { PD_MEM_HOST = 0, PD_MEM_DEVICE = 1 };
 enum { PD_F32 = 0, PD_F64 = 1 };
-enum { PD_IMPL_FAST = 0,  /* streaming fused kernels */
-       PD_IMPL_SIMPLE = 1 /* one-thread-per-pixel kernels, any image size; used as an on-GPU cross-check */ };
+/* How the peak stage is computed; every choice returns identical results. */
+enum { PD_IMPL_FAST = 0,   /* float32 candidate filter + exact float64 verification of the
+                              candidates where the source is network-resolution, else STREAM */
+       PD_IMPL_SIMPLE = 1, /* one-thread-per-pixel kernels, any image size; on-GPU cross-check */
+       PD_IMPL_STREAM = 2  /* exact float64 streaming kernel over every pixel */ };
 
 typedef struct pd_ctx pd_ctx;
 
@@ -175,7 +178,9 @@ enum {
     PD_STAGE_MATCH = 4,      /* per-limb sort + greedy matching */
     PD_STAGE_PARSE = 5,      /* person assembly */
     PD_STAGE_PACK = 6,       /* result packing */
-    PD_N_STAGES = 7
+    PD_STAGE_FILTER = 7,     /* float32 composite-kernel candidate filter */
+    PD_STAGE_VERIFY = 8,     /* exact float64 verification of the candidates */
+    PD_N_STAGES = 9
 };
 int pd_profile(pd_ctx* ctx, int enable);
 int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);

@@ -15,7 +15,7 @@ PD_OK, PD_E_INVALID, PD_E_HIP, PD_E_OVERFLOW, PD_E_INDEX, PD_E_STATE = 0, -1, -2
 MODE_P, MODE_D = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 F32, F64 = 0, 1
-IMPL_FAST, IMPL_SIMPLE = 0, 1
+IMPL_FAST, IMPL_SIMPLE, IMPL_STREAM = 0, 1, 2
 
 EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mode', 'pd_set_impl',
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
@@ -23,7 +23,7 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
            'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read']
 
-STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack']
+STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify']
 
 
 class Config(C.Structure):

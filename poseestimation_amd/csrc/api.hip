@@ -121,7 +121,8 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->pack_off, ctx->packed_peaks, ctx->packed_conns,
-                    ctx->packed_persons};
+                    ctx->packed_persons, ctx->kf_ystart, ctx->kf_ycoef, ctx->kf_xcoef, ctx->cand,
+                    ctx->cand_count};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->host_totals) (void)hipHostFree(ctx->host_totals);
@@ -142,7 +143,7 @@ extern "C" int pd_set_mode(pd_ctx* ctx, int mode) {
 
 extern "C" int pd_set_impl(pd_ctx* ctx, int impl) {
     PD_CHECK_CTX(ctx);
-    if (impl != PD_IMPL_FAST && impl != PD_IMPL_SIMPLE) PD_FAIL(ctx, PD_E_INVALID, "pd_set_impl: impl %d", impl);
+    if (impl != PD_IMPL_FAST && impl != PD_IMPL_SIMPLE && impl != PD_IMPL_STREAM) PD_FAIL(ctx, PD_E_INVALID, "pd_set_impl: impl %d", impl);
     ctx->impl = impl;
     return PD_OK;
 }

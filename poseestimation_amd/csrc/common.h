@@ -91,6 +91,16 @@ struct pd_ctx {
     TableSlot tabs[3];
     int tab_h, tab_w, tab_H, tab_W;  // what the slot-0 tables were built for
 
+    // ---- candidate filter (float32 composite of bicubic x8 and Gaussian) ----
+    int kf_ok;                       // tables valid for (kf_h, kf_w, kf_H, kf_W)
+    int kf_h, kf_w, kf_H, kf_W;
+    int32_t* kf_ystart;              // [H] first source row of the 8-tap window
+    float* kf_ycoef;                 // [H][8]
+    float* kf_xcoef;                 // [ceil(W/8)][10][7]
+    size_t kf_ycap, kf_xcap;
+    int32_t* cand;                   // [B][18][CK] packed (y << 16 | x)
+    int32_t* cand_count;             // [B][18]
+    int cand_cap;                    // CK
     // ---- peaks ----
     RawPeak* raw;        // [B][18][PK] unordered
     int32_t* raw_count;  // [B][18]
@@ -180,6 +190,10 @@ __device__ __forceinline__ float pd_bicubic_at(const float* __restrict__ img, in
 
 // ---- stage launchers (defined in the .hip files) --------------------------------
 int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed);
+int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smoothed,
+                           const int32_t* only_over, int over_limit);
+// PD_E_STATE when the geometry has no filter tables (caller falls back)
+int pd_launch_peaks_filtered(pd_ctx* ctx, double thr);
 int pd_launch_sort_peaks(pd_ctx* ctx);
 int pd_launch_pairs(pd_ctx* ctx, double thre2);
 int pd_launch_match(pd_ctx* ctx);

@@ -7,17 +7,9 @@
 // axis 1 (x); borders by half-sample reflection; a float32 source is rounded to
 // float32 after each axis.  NMS compares with >= against the four neighbours,
 // out-of-image neighbours count as 0.0, and requires value > threshold.
-#include "common.h"
+#include "colloader.h"
 
 #pragma clang fp contract(off)
-
-// scipy _gaussian_kernel1d(sigma=3, order=0, radius=12): weights of distance
-// 12, 11, .. 1, 0 (index 12 = centre).
-__constant__ double c_gw[PD_GTAPS] = {
-    0x1.763a210dfb306p-15, 0x1.4fbe39149e277p-13, 0x1.0d8a5ad43c165p-11, 0x1.8345966f69518p-10,
-    0x1.f1e9915139406p-9,  0x1.1e6bccad344bap-7,  0x1.26defcaeb0202p-6,  0x1.0fa58939b528fp-5,
-    0x1.bfde9c12bec92p-5,  0x1.4a614d1afd337p-4,  0x1.b42a57d56c0bep-4,  0x1.01a25f86eb137p-3,
-    0x1.105a329f98197p-3};
 
 struct SmoothArgs {
     MapSource src;
@@ -28,6 +20,10 @@ struct SmoothArgs {
     int32_t* raw_count;
     int PK;
     double* dbg;  // optional (B, 18, H, W)
+    // when set, only the (image, part) planes whose count exceeds over_limit are
+    // processed (planes the candidate filter could not hold)
+    const int32_t* only_over;
+    int over_limit;
 };
 
 __device__ __forceinline__ void emit_peak(bool is_peak, int y, int x, double score, RawPeak* list,
@@ -58,77 +54,6 @@ __device__ __forceinline__ void emit_peak(bool is_peak, int y, int x, double sco
 // once for the x pass, and the last three smoothed rows stay in registers for NMS.
 // ---------------------------------------------------------------------------------
 #define NTMAX 512
-
-template <int SRC>
-struct ColLoader;
-
-// Upsampled-on-the-fly column of a (h, w, C) float32 network output.
-template <>
-struct ColLoader<PD_SRC_LOWRES> {
-    const float* img;  // image b, channel offset applied
-    int h, w, C;
-    const int32_t* yofs;
-    const float* ycoef;
-    int xi0, xi1, xi2, xi3;
-    float a0, a1, a2, a3;
-    int cur;  // first tap row the cached horizontal sums belong to
-    float hv[4];
-
-    __device__ __forceinline__ float hrow(int s) const {
-        s = pd_clampi(s, 0, h - 1);
-        const float* row = img + ((size_t)s * w) * C;
-        return ((row[(size_t)xi0 * C] * a0 + row[(size_t)xi1 * C] * a1) + row[(size_t)xi2 * C] * a2) +
-               row[(size_t)xi3 * C] * a3;
-    }
-    __device__ __forceinline__ void init(const MapSource& s, int b, int ch, int col) {
-        img = s.lo + (size_t)b * s.h * s.w * s.C + ch;
-        h = s.h;
-        w = s.w;
-        C = s.C;
-        yofs = s.ty.ofs;
-        ycoef = s.ty.coef;
-        const int x0 = s.tx.ofs[col];
-        xi0 = pd_clampi(x0, 0, w - 1);
-        xi1 = pd_clampi(x0 + 1, 0, w - 1);
-        xi2 = pd_clampi(x0 + 2, 0, w - 1);
-        xi3 = pd_clampi(x0 + 3, 0, w - 1);
-        a0 = s.tx.coef[4 * col + 0];
-        a1 = s.tx.coef[4 * col + 1];
-        a2 = s.tx.coef[4 * col + 2];
-        a3 = s.tx.coef[4 * col + 3];
-        cur = -1000000;
-    }
-    __device__ __forceinline__ double load(int r) {
-        const int y0 = yofs[r];
-        if (y0 == cur + 1) {
-            hv[0] = hv[1];
-            hv[1] = hv[2];
-            hv[2] = hv[3];
-            hv[3] = hrow(y0 + 3);
-        } else if (y0 != cur) {
-            hv[0] = hrow(y0);
-            hv[1] = hrow(y0 + 1);
-            hv[2] = hrow(y0 + 2);
-            hv[3] = hrow(y0 + 3);
-        }
-        cur = y0;
-        const float v = ((hv[0] * ycoef[4 * r + 0] + hv[1] * ycoef[4 * r + 1]) + hv[2] * ycoef[4 * r + 2]) +
-                        hv[3] * ycoef[4 * r + 3];
-        return (double)v;
-    }
-};
-
-// Column of a float64 plane.
-template <>
-struct ColLoader<PD_SRC_FULLRES> {
-    const double* col;
-    int W;
-    __device__ __forceinline__ void init(const MapSource& s, int b, int ch, int c) {
-        col = s.full + ((size_t)b * s.Cfull + ch) * (size_t)s.H * s.W + c;
-        W = s.W;
-    }
-    __device__ __forceinline__ double load(int r) const { return col[(size_t)r * W]; }
-};
 
 __device__ __forceinline__ double round_store(double v, int f32mode) {
     return f32mode ? (double)(float)v : v;
@@ -196,6 +121,7 @@ k_smooth_nms_stream(SmoothArgs a) {
     __shared__ double sbuf[2 * (NTMAX + 2)];
     const int H = a.src.H, W = a.src.W;
     const int b = blockIdx.z, part = blockIdx.y, strip = blockIdx.x;
+    if (a.only_over != nullptr && a.only_over[b * PD_N_PARTS + part] <= a.over_limit) return;
     const int x0 = strip * a.strip_w;
     const int x1 = min(W, x0 + a.strip_w);
     const int xs = max(0, x0 - (PD_GR + 1));
@@ -327,6 +253,35 @@ static void pick_strips(int W, int* n_strips, int* strip_w, int* nt) {
     *nt = best_nt;
 }
 
+// The exact streaming kernel over all planes, or (only_over != NULL) over the planes
+// whose candidate count exceeded over_limit.
+int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smoothed,
+                           const int32_t* only_over, int over_limit) {
+    MapSource src = pd_heat_source(ctx);
+    SmoothArgs a;
+    a.src = src;
+    a.thr = thr;
+    a.f32mode = f32mode;
+    int nt;
+    pick_strips(ctx->W, &a.n_strips, &a.strip_w, &nt);
+    if (nt == 0) PD_FAIL(ctx, PD_E_INVALID, "no strip geometry for W=%d", ctx->W);
+    a.raw = ctx->raw;
+    a.raw_count = ctx->raw_count;
+    a.PK = ctx->cfg.max_peaks_per_part;
+    a.dbg = dbg_smoothed;
+    a.only_over = only_over;
+    a.over_limit = over_limit;
+    dim3 grid(a.n_strips, PD_N_PARTS, ctx->B);
+    pd_prof_begin(ctx, PD_STAGE_SMOOTH_NMS);
+    if (src.kind == PD_SRC_LOWRES)
+        hipLaunchKernelGGL(k_smooth_nms_stream<PD_SRC_LOWRES>, grid, dim3(nt), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_smooth_nms_stream<PD_SRC_FULLRES>, grid, dim3(nt), 0, ctx->stream, a);
+    pd_prof_end(ctx);
+    PD_HIP(ctx, hipGetLastError());
+    return PD_OK;
+}
+
 int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
     const int B = ctx->B, H = ctx->H, W = ctx->W;
     MapSource src = pd_heat_source(ctx);
@@ -336,28 +291,13 @@ int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
     // Python float in float32)
     const double thr = f32mode ? (double)(float)thre1 : thre1;
     const bool small = H < 2 * PD_GR + 2 || W < 2 * PD_GR + 2;
-    if (ctx->impl == PD_IMPL_FAST && !small) {
-        SmoothArgs a;
-        a.src = src;
-        a.thr = thr;
-        a.f32mode = f32mode;
-        int nt;
-        pick_strips(W, &a.n_strips, &a.strip_w, &nt);
-        if (nt == 0) PD_FAIL(ctx, PD_E_INVALID, "no strip geometry for W=%d", W);
-        a.raw = ctx->raw;
-        a.raw_count = ctx->raw_count;
-        a.PK = ctx->cfg.max_peaks_per_part;
-        a.dbg = dbg_smoothed;
-        dim3 grid(a.n_strips, PD_N_PARTS, B);
-        pd_prof_begin(ctx, PD_STAGE_SMOOTH_NMS);
-        if (src.kind == PD_SRC_LOWRES)
-            hipLaunchKernelGGL(k_smooth_nms_stream<PD_SRC_LOWRES>, grid, dim3(nt), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(k_smooth_nms_stream<PD_SRC_FULLRES>, grid, dim3(nt), 0, ctx->stream, a);
-        pd_prof_end(ctx);
-        PD_HIP(ctx, hipGetLastError());
-        return PD_OK;
+    if (ctx->impl == PD_IMPL_FAST && !small && src.kind == PD_SRC_LOWRES && dbg_smoothed == nullptr) {
+        // float32 candidate filter + exact verification; falls through to the
+        // streaming kernel when the geometry has no filter tables
+        int rc = pd_launch_peaks_filtered(ctx, thr);
+        if (rc != PD_E_STATE) return rc;
     }
+    if (ctx->impl != PD_IMPL_SIMPLE && !small) return pd_launch_stream_exact(ctx, thr, f32mode, dbg_smoothed, nullptr, 0);
     // simple path: materialise the 18 planes, filter axis 0 then axis 1, NMS
     const size_t n = (size_t)H * W;
     const size_t need = (size_t)B * PD_N_PARTS * n;

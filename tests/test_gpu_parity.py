@@ -102,10 +102,12 @@ def test_smoothing_is_bitwise_scipy(shape, dtype, impl):
 
 
 @pytest.mark.parametrize('name', gio.SCENES)
-@pytest.mark.parametrize('impl', [0, 1])
+@pytest.mark.parametrize('impl', [0, 1, 2])
 def test_fused_batch_mode_p_matches_reference_golden(pdec, name, impl):
     """Network outputs in, skeletons out, in one call: the fused path (bicubic on
-    the fly, nothing materialised) against the reference's outputs."""
+    the fly, nothing materialised) against the reference's outputs, for the three
+    peak-stage implementations (0 candidate filter + exact verification, 1 per-pixel,
+    2 exact streaming)."""
     g = gio.load(name)
     heat, paf = gio.scene_inputs(g)
     H, W = int(g['H']), int(g['W'])
@@ -120,6 +122,62 @@ def test_fused_batch_mode_p_matches_reference_golden(pdec, name, impl):
         gio.assert_conns_equal(conns, gio.conns_from(g['conns'], g['conns_limb'], g['conns_is_list']), RTOL)
         gio.assert_persons_equal(res.subset(b), g['persons'], RTOL)
     eng.close()
+
+
+def _lowres_case(kind, rng, h, w):
+    heat = np.zeros((2, h, w, 19), np.float32)
+    if kind == 'noise':            # peaks everywhere, values of both signs
+        heat[:] = rng.randn(2, h, w, 19) * 0.5
+    elif kind == 'big':            # large magnitudes: the filter tolerance scales with max |src|
+        heat[:] = rng.randn(2, h, w, 19) * 300.0
+    elif kind == 'plateau':        # constant blocks: exact ties between neighbours
+        heat[:, 5:12, 8:16, :] = 0.75
+        heat[1, 14:22, 3:11, 3] = 1.0
+    elif kind.startswith('ridge'):  # near-flat ridges: long runs of neighbours the filter cannot separate
+        yy = np.arange(h)[:, None] / h
+        xx = np.arange(w)[None, :] / w
+        for c in range(19):
+            heat[:, :, :, c] = (0.6 * np.exp(-((yy - 0.5 - 0.01 * c) ** 2) / 0.02) * (1 + 1e-7 * xx)).astype(np.float32)
+    elif kind == 'tiny_values':
+        heat[:] = rng.rand(2, h, w, 19) * 1e-6 + 0.2
+    paf = (rng.randn(2, h, w, 38) * 0.3).astype(np.float32)
+    return heat, paf
+
+
+@pytest.mark.parametrize('kind,thr,pk', [('noise', 0.1, 4096), ('noise', -0.2, 4096), ('big', 0.1, 4096),
+                                         ('plateau', 0.1, 4096), ('ridge', 0.1, 4096),
+                                         ('ridge_small_lists', 0.1, 64), ('tiny_values', 0.1, 4096)])
+@pytest.mark.parametrize('h,w,H,W', [(46, 46, 368, 368), (30, 41, 236, 323), (82, 82, 656, 656)])
+def test_candidate_filter_equals_exact_kernel(pdec, kind, thr, pk, h, w, H, W):
+    """The float32 candidate filter + exact verification (impl 0) must return exactly
+    the peaks of the exact float64 kernel over every pixel (impl 2), including on
+    inputs built to stress the filter's tolerance and, with short candidate lists, on
+    planes that fall back to the exact kernel."""
+    if kind == 'noise' and h == 82:
+        pytest.skip('covered at the smaller sizes')
+    from poseestimation_amd import _ffi
+    rng = np.random.RandomState(77)
+    heat, paf = _lowres_case(kind, rng, h, w)
+    out = []
+    for impl in (2, 0):
+        eng = pdec.DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='P', max_peaks_per_part=pk,
+                                max_persons=128, max_pairs_per_image=64)
+        eng.ctx.set_impl(impl)
+        eng.ctx.set_lowres(heat.ctypes.data, paf.ctypes.data, 2, h, w, H, W)
+        eng.ctx.peaks(thr)
+        eng.ctx.pack()
+        try:
+            out.append(eng.ctx.fetch())
+        except _ffi.DecodeOverflow:
+            assert impl == 2, 'the filtered path overflowed where the exact one did not'
+            pytest.skip('more true peaks than this case\'s lists hold')
+        finally:
+            eng.close()
+    assert out[0]['peaks'].size == out[1]['peaks'].size
+    np.testing.assert_array_equal(out[0]['part_count'], out[1]['part_count'])
+    assert np.array_equal(out[0]['peaks'], out[1]['peaks'])
+    if kind in ('noise', 'plateau', 'ridge'):
+        assert out[0]['peaks'].size > 0
 
 
 @pytest.mark.parametrize('seed,P,H,W', [(21, 4, 368, 368), (22, 6, 200, 312), (23, 1, 96, 96)])
