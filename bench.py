@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--mode', default='D', choices=['P', 'D'])
     ap.add_argument('--cpu-images', type=int, default=12, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--contexts', type=int, default=2, help='decode contexts (HIP streams) per GPU in ping-pong')
     args = ap.parse_args()
 
     import torch
@@ -63,36 +64,55 @@ def main():
     d_paf = torch.from_numpy(paf).cuda()
     torch.cuda.synchronize()
 
-    eng = DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=local_rank,
-                       max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000)
+    # two contexts (two HIP streams) in ping-pong: while the skeletons of batch i are
+    # copied out and gathered, the kernels of batch i+1 already run
+    engs = [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=local_rank,
+                         max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000)
+            for _ in range(args.contexts)]
+    eng = engs[0]
     gather_cap = 1 << 20
     while gather_cap < B * 16384:
         gather_cap <<= 1
 
-    def step():
-        eng.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
-        res = eng.ctx.fetch()            # waits for the stream, copies the packed skeletons to the host
+    def finish(e):
+        res = e.ctx.fetch()              # waits for that stream; packed skeletons now on the host
         if world > 1:
             return sharding.gather_results(res, gather_cap)
         return res
 
+    def run(nsteps):
+        """nsteps steps = nsteps batches decoded, fetched and (N > 1) gathered."""
+        pending, last = [], None
+        for i in range(nsteps):
+            e = engs[i % len(engs)]
+            if len(pending) == len(engs):
+                last = finish(pending.pop(0))
+            e.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
+            pending.append(e)
+        while pending:
+            last = finish(pending.pop(0))
+        return last
+
     def barrier():
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()         # device-wide: covers the contexts' own streams
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        last = step()
-    eng.ctx.profile(True)
+    last = run(args.warmup)
+    for e in engs:
+        e.ctx.profile(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
+    last = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    prof = eng.ctx.profile_read()
-    eng.ctx.profile(False)
+    prof = {}
+    for e in engs:
+        for k, v in e.ctx.profile_read().items():
+            a = prof.get(k, (0.0, 0))
+            prof[k] = (a[0] + v[0], a[1] + v[1])
+        e.ctx.profile(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -102,11 +122,14 @@ def main():
     if rank == 0:
         images = world * B * args.steps
         n, N = h * w, H * W
-        # dominant kernel: Gaussian + NMS over the 18 part channels, fed by the x8
-        # bicubic upsample evaluated on the fly.  Algorithmic bytes per image of that
-        # kernel's share: upsample read 18*n*4 + write 18*N*4, Gaussian read + write
-        # 2*18*N*4, NMS read 18*N*4  =  72*n + 288*N.
-        sm_ms, sm_n = prof['smooth_nms']
+        # dominant kernel: the peak stage's pass over every pixel of the 18 part
+        # channels (upsample x8 + Gaussian + NMS in one kernel: k_prefilter, or
+        # k_smooth_nms_stream when the exact kernel runs alone).  Algorithmic bytes per
+        # image of that stage: upsample read 18*n*4 + write 18*N*4, Gaussian read +
+        # write 2*18*N*4, NMS read 18*N*4  =  72*n + 288*N.
+        kname, kstage = ('k_prefilter', 'filter') if prof.get('filter', (0, 0))[1] else \
+            ('k_smooth_nms_stream', 'smooth_nms')
+        sm_ms, sm_n = prof[kstage]
         alg_bytes = B * (72.0 * n + 288.0 * N)
         avg_s = (sm_ms / max(sm_n, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
@@ -127,7 +150,7 @@ def main():
             'config': {'workload': desc, 'batch_per_gpu': B, 'mode': args.mode,
                        'people_per_image': list(people) if isinstance(people, tuple) else people,
                        'outputs': 'packed skeleton lists copied to the host every step'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_smooth_nms_stream', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': sm_n,
                          'algorithmic_bytes_per_launch': alg_bytes},

@@ -159,6 +159,13 @@ int pd_sync_totals(pd_ctx* ctx, pd_totals* totals);
 int pd_fetch(pd_ctx* ctx, int32_t* part_count, int32_t* limb_count, int32_t* person_count,
              int32_t* status, pd_peak* peaks, pd_conn* conns, double* persons);
 
+/* The packed results in the context's own pinned host buffer, without a copy: valid
+ * until the next stage call on this context.  Layout: int64 header[8] = {B, n_peaks,
+ * n_conns, n_persons, first_bad_image, 0, 0, 0}; int32 part_count[B][18],
+ * limb_count[B][19], person_count[B], status[B]; then, 16-byte aligned, pd_peak[n_peaks],
+ * pd_conn[n_conns], double[n_persons][20]. */
+int pd_results_host(pd_ctx* ctx, const void** base, uint64_t* nbytes);
+
 /* Device addresses of the packed results and count tables (valid after
  * pd_sync_totals until the next stage call on this context), for callers that
  * forward them without a host round trip (e.g. a collective gather).  Any output

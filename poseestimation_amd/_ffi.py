@@ -21,7 +21,7 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host']
 
 STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify']
 
@@ -40,6 +40,39 @@ class Totals(C.Structure):
 PEAK_DTYPE = np.dtype([('y', np.int32), ('x', np.int32), ('score', np.float64)])
 CONN_DTYPE = np.dtype([('id_a', np.int32), ('id_b', np.int32), ('ia', np.int32), ('ib', np.int32),
                        ('score', np.float64)])
+
+
+def res_layout(B):
+    """Byte offsets inside the packed result buffer (ResLayout in csrc/common.h)."""
+    off_part = 64
+    off_limb = off_part + B * 18 * 4
+    off_pers = off_limb + B * 19 * 4
+    off_stat = off_pers + B * 4
+    off_payload = (off_stat + B * 4 + 15) & ~15
+    return off_part, off_limb, off_pers, off_stat, off_payload
+
+
+def unpack_results(raw, B=None):
+    """uint8 image of the packed result buffer -> dict of numpy views."""
+    head = raw[:64].view(np.int64)
+    if B is None:
+        B = int(head[0])
+    npk, ncn, nps = int(head[1]), int(head[2]), int(head[3])
+    off_part, off_limb, off_pers, off_stat, off_pay = res_layout(B)
+    p1 = off_pay + npk * PEAK_DTYPE.itemsize
+    p2 = p1 + ncn * CONN_DTYPE.itemsize
+    p3 = p2 + nps * 160
+    return {
+        'B': B,
+        'part_count': raw[off_part:off_limb].view(np.int32).reshape(B, 18),
+        'limb_count': raw[off_limb:off_pers].view(np.int32).reshape(B, 19),
+        'person_count': raw[off_pers:off_stat].view(np.int32),
+        'status': raw[off_stat:off_stat + 4 * B].view(np.int32),
+        'peaks': raw[off_pay:p1].view(PEAK_DTYPE),
+        'conns': raw[p1:p2].view(CONN_DTYPE),
+        'persons': raw[p2:p3].view(np.float64).reshape(nps, 20),
+        'raw': raw[:p3],
+    }
 
 
 class DecodeOverflow(RuntimeError):
@@ -86,6 +119,7 @@ def lib():
     L.pd_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.pd_debug_smoothed.argtypes = [vp, vp]
     L.pd_packed_device.argtypes = [vp] + [C.POINTER(vp)] * 6
+    L.pd_results_host.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.pd_profile.argtypes = [vp, i32]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
@@ -223,7 +257,17 @@ class Context:
         return t
 
     def fetch(self):
-        """Packed results of the stages that ran, as numpy arrays."""
+        """Packed results of the stages that ran, as numpy arrays (one copy out of
+        the context's pinned result buffer)."""
+        t = self.sync_totals()      # waits; raises on overflow / mode-D index error
+        base = C.c_void_p()
+        nbytes = C.c_uint64()
+        self.check(self.L.pd_results_host(self._h, C.byref(base), C.byref(nbytes)))
+        raw = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_uint8)), shape=(nbytes.value,)).copy()
+        return unpack_results(raw, t.n_images)
+
+    def fetch_via_pd_fetch(self):
+        """The same through pd_fetch (caller-allocated arrays)."""
         t = self.sync_totals()
         B = t.n_images
         out = {

@@ -95,10 +95,16 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     CR(dev_alloc(ctx, (void**)&ctx->person_count, B * sizeof(int32_t)));
     CR(dev_alloc(ctx, (void**)&ctx->status, B * sizeof(int32_t)));
     CR(dev_alloc(ctx, (void**)&ctx->pack_off, (3 * (B + 1) + 4) * sizeof(int64_t)));
-    CR(dev_alloc(ctx, (void**)&ctx->packed_peaks, B * PD_N_PARTS * PK * sizeof(pd_peak)));
-    CR(dev_alloc(ctx, (void**)&ctx->packed_conns, B * PD_N_LIMBS * PK * sizeof(pd_conn)));
-    CR(dev_alloc(ctx, (void**)&ctx->packed_persons, B * (size_t)cfg->max_persons * 20 * sizeof(double)));
-    CRH(hipHostMalloc((void**)&ctx->host_totals, 4 * sizeof(int64_t), hipHostMallocDefault));
+    {
+        const ResLayout lay = pd_res_layout((int)B);
+        ctx->res_cap = lay.off_payload + B * PD_N_PARTS * PK * sizeof(pd_peak) + B * PD_N_LIMBS * PK * sizeof(pd_conn) +
+                       B * (size_t)cfg->max_persons * 20 * sizeof(double);
+        // typical images need a few KB; anything beyond the speculative prefix costs a second copy
+        ctx->res_spec = lay.off_payload + 65536 + B * 6144;
+        if (ctx->res_spec > ctx->res_cap) ctx->res_spec = ctx->res_cap;
+    }
+    CR(dev_alloc(ctx, (void**)&ctx->res_dev, ctx->res_cap));
+    CRH(hipHostMalloc((void**)&ctx->res_host, ctx->res_cap, hipHostMallocDefault));
     CRH(hipMemset(ctx->status, 0, B * sizeof(int32_t)));
     if (cfg->fullres) {
         const size_t n = (size_t)cfg->max_h * cfg->max_w;
@@ -120,12 +126,11 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->tabs[1].f, ctx->tabs[2].i, ctx->tabs[2].f, ctx->raw, ctx->raw_count, ctx->pk_y,
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
-                    ctx->person_count, ctx->status, ctx->pack_off, ctx->packed_peaks, ctx->packed_conns,
-                    ctx->packed_persons, ctx->kf_ystart, ctx->kf_ycoef, ctx->kf_xcoef, ctx->cand,
+                    ctx->person_count, ctx->status, ctx->pack_off, ctx->res_dev, ctx->kf_ystart, ctx->kf_ycoef, ctx->kf_xcoef, ctx->cand,
                     ctx->cand_count};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    if (ctx->host_totals) (void)hipHostFree(ctx->host_totals);
+    if (ctx->res_host) (void)hipHostFree(ctx->res_host);
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
     free(ctx->prof_stage);
@@ -511,9 +516,29 @@ extern "C" int pd_pack(pd_ctx* ctx) {
     if (!ctx->have_peaks && !ctx->have_conns && !ctx->have_persons) PD_FAIL(ctx, PD_E_STATE, "pd_pack: nothing to pack");
     int rc = pd_launch_pack(ctx);
     if (rc != PD_OK) return rc;
-    const int64_t* dev_totals = ctx->pack_off + 3 * ((size_t)ctx->cfg.max_batch + 1);
-    PD_HIP(ctx, hipMemcpyAsync(ctx->host_totals, dev_totals, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    // header, count tables and (speculatively) the head of the payload in one copy
+    const ResLayout lay = pd_res_layout(ctx->B);
+    size_t spec = lay.off_payload + 65536 + (size_t)ctx->B * 6144;
+    if (spec > ctx->res_cap) spec = ctx->res_cap;
+    PD_HIP(ctx, hipMemcpyAsync(ctx->res_host, ctx->res_dev, spec, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->res_have = spec;
     ctx->packed = 1;
+    return PD_OK;
+}
+
+// Waits for the packed results and completes the host mirror.
+static int finish_results(pd_ctx* ctx) {
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t* head = (const int64_t*)ctx->res_host;
+    const ResLayout lay = pd_res_layout(ctx->B);
+    const size_t end = lay.off_payload + (size_t)head[1] * sizeof(pd_peak) + (size_t)head[2] * sizeof(pd_conn) +
+                       (size_t)head[3] * 20 * sizeof(double);
+    if (end > ctx->res_have) {
+        PD_HIP(ctx, hipMemcpyAsync(ctx->res_host + ctx->res_have, ctx->res_dev + ctx->res_have, end - ctx->res_have,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->res_have = end;
+    }
     return PD_OK;
 }
 
@@ -588,9 +613,13 @@ extern "C" int pd_packed_device(pd_ctx* ctx, void** peaks, void** conns, void** 
                                 void** limb_count, void** person_count) {
     PD_CHECK_CTX(ctx);
     if (!ctx->packed) PD_FAIL(ctx, PD_E_STATE, "pd_packed_device: call pd_pack (or a decode entry point) first");
-    if (peaks) *peaks = ctx->packed_peaks;
-    if (conns) *conns = ctx->packed_conns;
-    if (persons) *persons = ctx->packed_persons;
+    int rc = finish_results(ctx);
+    if (rc != PD_OK) return rc;
+    const int64_t* head = (const int64_t*)ctx->res_host;
+    unsigned char* pay = ctx->res_dev + pd_res_layout(ctx->B).off_payload;
+    if (peaks) *peaks = pay;
+    if (conns) *conns = pay + (size_t)head[1] * sizeof(pd_peak);
+    if (persons) *persons = pay + (size_t)head[1] * sizeof(pd_peak) + (size_t)head[2] * sizeof(pd_conn);
     if (part_count) *part_count = ctx->part_count;
     if (limb_count) *limb_count = ctx->limb_count;
     if (person_count) *person_count = ctx->person_count;
@@ -601,22 +630,34 @@ extern "C" int pd_sync_totals(pd_ctx* ctx, pd_totals* totals) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     if (!ctx->packed) PD_FAIL(ctx, PD_E_STATE, "pd_sync_totals: call pd_pack (or a decode entry point) first");
-    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = finish_results(ctx);
+    if (rc != PD_OK) return rc;
+    const int64_t* head = (const int64_t*)ctx->res_host;
     if (totals) {
         totals->n_images = ctx->B;
-        totals->n_peaks = ctx->host_totals[0];
-        totals->n_conns = ctx->host_totals[1];
-        totals->n_persons = ctx->host_totals[2];
-        totals->first_bad_image = (int32_t)ctx->host_totals[3];
+        totals->n_peaks = head[1];
+        totals->n_conns = head[2];
+        totals->n_persons = head[3];
+        totals->first_bad_image = (int32_t)head[4];
     }
-    if (ctx->host_totals[3] >= 0) {
-        int32_t st = 0;
-        PD_HIP(ctx, hipMemcpy(&st, ctx->status + ctx->host_totals[3], sizeof(st), hipMemcpyDeviceToHost));
+    if (head[4] >= 0) {
+        const int32_t st = ((const int32_t*)(ctx->res_host + pd_res_layout(ctx->B).off_stat))[head[4]];
         if (st == PD_E_INDEX)
-            PD_FAIL(ctx, PD_E_INDEX, "image %lld: a connection touches more than two persons (predict.py:199 IndexError)", (long long)ctx->host_totals[3]);
+            PD_FAIL(ctx, PD_E_INDEX, "image %lld: a connection touches more than two persons (predict.py:199 IndexError)", (long long)head[4]);
         PD_FAIL(ctx, PD_E_OVERFLOW, "image %lld: a capacity of the context was exceeded (peaks per part %d, pairs %d, persons %d)",
-                (long long)ctx->host_totals[3], ctx->cfg.max_peaks_per_part, ctx->cfg.max_pairs_per_image, ctx->cfg.max_persons);
+                (long long)head[4], ctx->cfg.max_peaks_per_part, ctx->cfg.max_pairs_per_image, ctx->cfg.max_persons);
     }
+    return PD_OK;
+}
+
+extern "C" int pd_results_host(pd_ctx* ctx, const void** base, uint64_t* nbytes) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!ctx->packed) PD_FAIL(ctx, PD_E_STATE, "pd_results_host: call pd_pack (or a decode entry point) first");
+    int rc = finish_results(ctx);
+    if (rc != PD_OK) return rc;
+    if (base) *base = ctx->res_host;
+    if (nbytes) *nbytes = ctx->res_have;
     return PD_OK;
 }
 
@@ -625,22 +666,21 @@ extern "C" int pd_fetch(pd_ctx* ctx, int32_t* part_count, int32_t* limb_count, i
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     if (!ctx->packed) PD_FAIL(ctx, PD_E_STATE, "pd_fetch: call pd_pack (or a decode entry point) first");
-    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = finish_results(ctx);
+    if (rc != PD_OK) return rc;
     const size_t B = ctx->B;
-    hipStream_t s = ctx->stream;
-    if (part_count && ctx->have_peaks)
-        PD_HIP(ctx, hipMemcpyAsync(part_count, ctx->part_count, B * PD_N_PARTS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (limb_count && ctx->have_conns)
-        PD_HIP(ctx, hipMemcpyAsync(limb_count, ctx->limb_count, B * PD_N_LIMBS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (person_count && ctx->have_persons)
-        PD_HIP(ctx, hipMemcpyAsync(person_count, ctx->person_count, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (status) PD_HIP(ctx, hipMemcpyAsync(status, ctx->status, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (peaks && ctx->have_peaks && ctx->host_totals[0] > 0)
-        PD_HIP(ctx, hipMemcpyAsync(peaks, ctx->packed_peaks, ctx->host_totals[0] * sizeof(pd_peak), hipMemcpyDeviceToHost, s));
-    if (conns && ctx->have_conns && ctx->host_totals[1] > 0)
-        PD_HIP(ctx, hipMemcpyAsync(conns, ctx->packed_conns, ctx->host_totals[1] * sizeof(pd_conn), hipMemcpyDeviceToHost, s));
-    if (persons && ctx->have_persons && ctx->host_totals[2] > 0)
-        PD_HIP(ctx, hipMemcpyAsync(persons, ctx->packed_persons, ctx->host_totals[2] * 20 * sizeof(double), hipMemcpyDeviceToHost, s));
-    PD_HIP(ctx, hipStreamSynchronize(s));
+    const ResLayout lay = pd_res_layout(ctx->B);
+    const unsigned char* r = ctx->res_host;
+    const int64_t* head = (const int64_t*)r;
+    const unsigned char* pay = r + lay.off_payload;
+    if (part_count) memcpy(part_count, r + lay.off_part, B * PD_N_PARTS * sizeof(int32_t));
+    if (limb_count) memcpy(limb_count, r + lay.off_limb, B * PD_N_LIMBS * sizeof(int32_t));
+    if (person_count) memcpy(person_count, r + lay.off_pers, B * sizeof(int32_t));
+    if (status) memcpy(status, r + lay.off_stat, B * sizeof(int32_t));
+    if (peaks) memcpy(peaks, pay, (size_t)head[1] * sizeof(pd_peak));
+    if (conns) memcpy(conns, pay + (size_t)head[1] * sizeof(pd_peak), (size_t)head[2] * sizeof(pd_conn));
+    if (persons)
+        memcpy(persons, pay + (size_t)head[1] * sizeof(pd_peak) + (size_t)head[2] * sizeof(pd_conn),
+               (size_t)head[3] * 20 * sizeof(double));
     return PD_OK;
 }

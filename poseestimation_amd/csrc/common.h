@@ -51,6 +51,23 @@ struct MapSource {
     CubicTable ty, tx;    // x8 tables of length H and W
 };
 
+// Byte layout of the packed result buffer of a batch of B images:
+//   int64 header[8]: B, n_peaks, n_conns, n_persons, first_bad_image (or -1), 0, 0, 0
+//   int32 part_count[B][18], limb_count[B][19], person_count[B], status[B]
+//   (16-byte aligned) pd_peak[n_peaks], pd_conn[n_conns], double[n_persons][20]
+struct ResLayout {
+    size_t off_part, off_limb, off_pers, off_stat, off_payload;
+};
+__host__ __device__ inline ResLayout pd_res_layout(int B) {
+    ResLayout l;
+    l.off_part = 64;
+    l.off_limb = l.off_part + (size_t)B * PD_N_PARTS * 4;
+    l.off_pers = l.off_limb + (size_t)B * PD_N_LIMBS * 4;
+    l.off_stat = l.off_pers + (size_t)B * 4;
+    l.off_payload = (l.off_stat + (size_t)B * 4 + 15) & ~(size_t)15;
+    return l;
+}
+
 struct TableSlot {
     int32_t* i;
     float* f;
@@ -120,10 +137,12 @@ struct pd_ctx {
     int32_t* status;        // [B]
     // ---- packed results ----
     int64_t* pack_off;  // [3][B+1] exclusive prefixes: peaks, conns, persons
-    pd_peak* packed_peaks;
-    pd_conn* packed_conns;
-    double* packed_persons;
-    int64_t* host_totals;  // pinned: [3] totals + first_bad
+    // one contiguous result buffer (see ResLayout) on the device and its pinned
+    // host mirror; res_spec bytes are copied speculatively right behind the pack
+    // kernel, the remainder (if any) once the totals are known
+    unsigned char* res_dev;
+    unsigned char* res_host;
+    size_t res_cap, res_spec, res_have;
     int have_peaks, have_conns, have_persons, packed;
     // ---- stage timing (pd_profile) ----
     int prof_on, prof_n, prof_cap;

@@ -130,10 +130,8 @@ struct PackArgs {
     const pd_conn* conn;
     const double* persons;
     int64_t* pack_off;  // [3][B+1]
-    pd_peak* out_peaks;
-    pd_conn* out_conns;
-    double* out_persons;
-    int64_t* totals;    // [4] device copy: peaks, conns, persons, first bad image
+    unsigned char* res; // result buffer: header | count tables | peaks | conns | persons
+    ResLayout lay;
 };
 
 // Exclusive prefix sums over the images (one workgroup; B is at most a few thousand).
@@ -165,11 +163,12 @@ k_pack_offsets(PackArgs a) {
                 s_part[q][t] = run;
                 run += v;
             }
-            a.totals[q] = run;
+            ((int64_t*)a.res)[1 + q] = run;
             a.pack_off[q * (a.B + 1) + a.B] = run;
         }
         for (int t = 0; t < 256; ++t) fb = min(fb, s_bad[t]);
-        a.totals[3] = fb == 0x7fffffff ? -1 : fb;
+        ((int64_t*)a.res)[0] = a.B;
+        ((int64_t*)a.res)[4] = fb == 0x7fffffff ? -1 : fb;
     }
     __syncthreads();
     long long run[3] = {s_part[0][tid], s_part[1][tid], s_part[2][tid]};
@@ -186,8 +185,19 @@ __global__ void __launch_bounds__(128)
 k_pack(PackArgs a) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    // count tables of this image
+    if (tid < PD_N_PARTS) ((int32_t*)(a.res + a.lay.off_part))[b * PD_N_PARTS + tid] = a.have_peaks ? a.part_count[b * PD_N_PARTS + tid] : 0;
+    if (tid < PD_N_LIMBS) ((int32_t*)(a.res + a.lay.off_limb))[b * PD_N_LIMBS + tid] = a.have_conns ? a.limb_count[b * PD_N_LIMBS + tid] : 0;
+    if (tid == 0) {
+        ((int32_t*)(a.res + a.lay.off_pers))[b] = a.have_persons ? a.person_count[b] : 0;
+        ((int32_t*)(a.res + a.lay.off_stat))[b] = a.status[b];
+    }
+    const int64_t n_peaks = a.pack_off[a.B], n_conns = a.pack_off[(a.B + 1) + a.B];
+    pd_peak* out_peaks = (pd_peak*)(a.res + a.lay.off_payload);
+    pd_conn* out_conns = (pd_conn*)(a.res + a.lay.off_payload + n_peaks * sizeof(pd_peak));
+    double* out_persons = (double*)(a.res + a.lay.off_payload + n_peaks * sizeof(pd_peak) + n_conns * sizeof(pd_conn));
     if (a.have_peaks) {
-        pd_peak* out = a.out_peaks + a.pack_off[b];
+        pd_peak* out = out_peaks + a.pack_off[b];
         for (int p = 0; p < PD_N_PARTS; ++p) {
             const int n = a.part_count[b * PD_N_PARTS + p];
             const int base = a.part_base[b * (PD_N_PARTS + 1) + p];
@@ -202,7 +212,7 @@ k_pack(PackArgs a) {
         }
     }
     if (a.have_conns) {
-        pd_conn* out = a.out_conns + a.pack_off[(a.B + 1) + b];
+        pd_conn* out = out_conns + a.pack_off[(a.B + 1) + b];
         int run = 0;
         for (int k = 0; k < PD_N_LIMBS; ++k) {
             const int n = max(0, a.limb_count[b * PD_N_LIMBS + k]);
@@ -212,7 +222,7 @@ k_pack(PackArgs a) {
         }
     }
     if (a.have_persons) {
-        double* out = a.out_persons + a.pack_off[2 * (a.B + 1) + b] * 20;
+        double* out = out_persons + a.pack_off[2 * (a.B + 1) + b] * 20;
         const int n = a.person_count[b] * 20;
         const double* src = a.persons + (size_t)b * a.max_persons * 20;
         for (int i = tid; i < n; i += blockDim.x) out[i] = src[i];
@@ -257,10 +267,8 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.conn = ctx->conn;
     a.persons = ctx->persons;
     a.pack_off = ctx->pack_off;
-    a.out_peaks = ctx->packed_peaks;
-    a.out_conns = ctx->packed_conns;
-    a.out_persons = ctx->packed_persons;
-    a.totals = ctx->pack_off + 3 * ((size_t)ctx->cfg.max_batch + 1);
+    a.res = ctx->res_dev;
+    a.lay = pd_res_layout(ctx->B);
     pd_prof_begin(ctx, PD_STAGE_PACK);
     hipLaunchKernelGGL(k_pack_offsets, dim3(1), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(128), 0, ctx->stream, a);

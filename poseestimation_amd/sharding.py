@@ -9,9 +9,7 @@ Rank-major order of the gathered blocks is the original image order.
 """
 import numpy as np
 
-from ._ffi import CONN_DTYPE, PEAK_DTYPE
-
-_MAGIC = 0x50444B31  # "PDK1"
+from ._ffi import CONN_DTYPE, PEAK_DTYPE, res_layout, unpack_results
 
 
 def shard_range(n_images, world_size, rank):
@@ -22,51 +20,39 @@ def shard_range(n_images, world_size, rank):
 
 
 def pack_blob(res):
-    """Serialise the packed results of one rank (the dict of ``Context.fetch``) into a
-    flat uint8 array: header, count tables, then peaks / connections / persons."""
+    """The packed results of one rank as a flat uint8 array in the library's own
+    result-buffer layout (header, count tables, peaks, connections, persons).  A dict
+    that came from ``Context.fetch`` already carries that image as ``res['raw']``."""
+    if 'raw' in res:
+        return res['raw']
     B = int(res['B'])
-    head = np.array([_MAGIC, B, len(res['peaks']), len(res['conns']), len(res['persons'])], np.int64)
-    parts = [head.view(np.uint8),
-             np.ascontiguousarray(res['part_count'], np.int32).view(np.uint8).ravel(),
-             np.ascontiguousarray(res['limb_count'], np.int32).view(np.uint8).ravel(),
-             np.ascontiguousarray(res['person_count'], np.int32).view(np.uint8).ravel(),
-             np.ascontiguousarray(res['status'], np.int32).view(np.uint8).ravel(),
-             np.ascontiguousarray(res['peaks']).view(np.uint8).ravel(),
-             np.ascontiguousarray(res['conns']).view(np.uint8).ravel(),
-             np.ascontiguousarray(res['persons'], np.float64).view(np.uint8).ravel()]
-    return np.concatenate(parts)
+    off_part, off_limb, off_pers, off_stat, off_pay = res_layout(B)
+    npk, ncn, nps = len(res['peaks']), len(res['conns']), len(res['persons'])
+    raw = np.zeros(off_pay + npk * PEAK_DTYPE.itemsize + ncn * CONN_DTYPE.itemsize + nps * 160, np.uint8)
+    raw[:64].view(np.int64)[:5] = [B, npk, ncn, nps, -1]
+    raw[off_part:off_limb] = np.ascontiguousarray(res['part_count'], np.int32).view(np.uint8).ravel()
+    raw[off_limb:off_pers] = np.ascontiguousarray(res['limb_count'], np.int32).view(np.uint8).ravel()
+    raw[off_pers:off_stat] = np.ascontiguousarray(res['person_count'], np.int32).view(np.uint8).ravel()
+    raw[off_stat:off_stat + 4 * B] = np.ascontiguousarray(res['status'], np.int32).view(np.uint8).ravel()
+    p1 = off_pay + npk * PEAK_DTYPE.itemsize
+    p2 = p1 + ncn * CONN_DTYPE.itemsize
+    raw[off_pay:p1] = np.ascontiguousarray(res['peaks']).view(np.uint8).ravel()
+    raw[p1:p2] = np.ascontiguousarray(res['conns']).view(np.uint8).ravel()
+    raw[p2:] = np.ascontiguousarray(res['persons'], np.float64).view(np.uint8).ravel()
+    return raw
 
 
 def blob_nbytes(blob):
-    head = np.frombuffer(blob[:40].tobytes(), np.int64)
-    if head[0] != _MAGIC:
+    head = np.ascontiguousarray(blob[:64]).view(np.int64)
+    B, npk, ncn, nps = (int(v) for v in head[:4])
+    if B < 0 or npk < 0 or ncn < 0 or nps < 0:
         raise ValueError('not a result blob')
-    B, npk, ncn, nps = (int(v) for v in head[1:5])
-    return 40 + B * (18 + 19 + 1 + 1) * 4 + npk * PEAK_DTYPE.itemsize + ncn * CONN_DTYPE.itemsize + nps * 160
+    return res_layout(B)[4] + npk * PEAK_DTYPE.itemsize + ncn * CONN_DTYPE.itemsize + nps * 160
 
 
 def unpack_blob(blob):
     blob = np.ascontiguousarray(blob, np.uint8)
-    head = np.frombuffer(blob[:40].tobytes(), np.int64)
-    if head[0] != _MAGIC:
-        raise ValueError('not a result blob')
-    B, npk, ncn, nps = (int(v) for v in head[1:5])
-    at = [40]
-
-    def take(nbytes, dtype, shape):
-        a = np.frombuffer(blob[at[0]:at[0] + nbytes].tobytes(), dtype).reshape(shape)
-        at[0] += nbytes
-        return a
-    return {
-        'B': B,
-        'part_count': take(B * 18 * 4, np.int32, (B, 18)),
-        'limb_count': take(B * 19 * 4, np.int32, (B, 19)),
-        'person_count': take(B * 4, np.int32, (B,)),
-        'status': take(B * 4, np.int32, (B,)),
-        'peaks': take(npk * PEAK_DTYPE.itemsize, PEAK_DTYPE, (npk,)),
-        'conns': take(ncn * CONN_DTYPE.itemsize, CONN_DTYPE, (ncn,)),
-        'persons': take(nps * 160, np.float64, (nps, 20)),
-    }
+    return unpack_results(blob[:blob_nbytes(blob)].copy())
 
 
 def concat_results(parts):
