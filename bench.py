@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--mode', default='D', choices=['P', 'D'])
     ap.add_argument('--cpu-images', type=int, default=12, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--people', type=int, default=0, help='experiments: fixed people per image')
     ap.add_argument('--contexts', type=int, default=2, help='decode contexts (HIP streams) per GPU in ping-pong')
     args = ap.parse_args()
 
@@ -58,6 +59,9 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     B, H, W, people, desc = WORKLOADS[args.workload]
+    if args.people:      # experiments only: a fixed number of people per image
+        people = args.people
+        desc += ' (people per image overridden: %d)' % people
     h, w = H // 8, W // 8
     heat, paf = synth.batch(B, H, W, people, seed0=rank * B, paf_order='xy' if args.mode == 'D' else 'yx')
     d_heat = torch.from_numpy(heat).cuda()

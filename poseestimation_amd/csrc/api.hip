@@ -57,6 +57,7 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     ctx->cfg = *cfg;
     ctx->mode = PD_MODE_P;
     ctx->impl = PD_IMPL_FAST;
+    ctx->use_graph = getenv("PD_NO_GRAPH") ? 0 : 1;
 #define CR(call)                                                                     \
     do {                                                                             \
         int rc_ = (call);                                                            \
@@ -127,11 +128,13 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->pack_off, ctx->res_dev, ctx->kf_ystart, ctx->kf_ycoef, ctx->kf_xcoef, ctx->cand,
-                    ctx->cand_count};
+                    ctx->cand_count, ctx->absmax, ctx->heat_planar};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->res_host) (void)hipHostFree(ctx->res_host);
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+    free(ctx->kf_ystart_host);
     free(ctx->prof_ev);
     free(ctx->prof_stage);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -526,9 +529,33 @@ extern "C" int pd_pack(pd_ctx* ctx) {
     return PD_OK;
 }
 
+// Folds the event pairs recorded since the last harvest into the per-stage sums.
+// The stream must be idle.
+static int prof_harvest(pd_ctx* ctx) {
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) != hipSuccess) {
+            // events replayed from a graph could not be read on this runtime: drop the
+            // sample and go back to eager launches, which always can
+            (void)hipGetLastError();
+            ctx->use_graph = 0;
+            break;
+        }
+        const int s = ctx->prof_stage[i];
+        ctx->prof_ms[s] += (double)t;
+        ctx->prof_cnt[s] += 1;
+    }
+    ctx->prof_n = 0;
+    return PD_OK;
+}
+
 // Waits for the packed results and completes the host mirror.
 static int finish_results(pd_ctx* ctx) {
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->prof_n > 0) {
+        int rc = prof_harvest(ctx);
+        if (rc != PD_OK) return rc;
+    }
     const int64_t* head = (const int64_t*)ctx->res_host;
     const ResLayout lay = pd_res_layout(ctx->B);
     const size_t end = lay.off_payload + (size_t)head[1] * sizeof(pd_peak) + (size_t)head[2] * sizeof(pd_conn) +
@@ -558,7 +585,72 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     if (!heat || !paf) PD_FAIL(ctx, PD_E_INVALID, "pd_decode_batch: heat and paf are required");
     int rc = pd_set_lowres(ctx, heat, paf, B, h, w, H, W, mem);
     if (rc != PD_OK) return rc;
-    return pd_decode_fullres(ctx, thre1, thre2);
+    if (mem != PD_MEM_DEVICE || !ctx->use_graph) return pd_decode_fullres(ctx, thre1, thre2);
+
+    // Device-resident input: the whole launch sequence (about a dozen kernels, three
+    // memsets, the result copy and, when profiling, the event pairs) is captured into a
+    // HIP graph the second time the same call is seen and replayed from then on, which
+    // takes the per-launch host cost out of the steady state.
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.heat = heat;
+    key.paf = paf;
+    key.B = B;
+    key.h = h;
+    key.w = w;
+    key.H = H;
+    key.W = W;
+    key.t1 = thre1;
+    key.t2 = thre2;
+    key.mode = ctx->mode;
+    key.impl = ctx->impl;
+    key.prof = ctx->prof_on;
+    if (ctx->graph_exec && memcmp(&key, &ctx->graph_key, sizeof(key)) == 0) {
+        PD_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+        ctx->have_peaks = ctx->have_conns = ctx->have_persons = ctx->packed = 1;
+        ctx->res_have = ctx->graph_res_have;
+        ctx->prof_n = ctx->graph_prof_n;
+        return PD_OK;
+    }
+    if (memcmp(&key, &ctx->graph_seen, sizeof(key)) != 0) {
+        // first sight of this call: run it eagerly (this also makes every lazy allocation)
+        ctx->graph_seen = key;
+        return pd_decode_fullres(ctx, thre1, thre2);
+    }
+    if (ctx->graph_exec) {
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PD_HIP(ctx, hipGraphExecDestroy(ctx->graph_exec));
+        ctx->graph_exec = nullptr;
+    }
+    if (ctx->prof_n > 0) {  // pairs of earlier eager calls must not be mixed into the captured set
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = prof_harvest(ctx);
+        if (rc != PD_OK) return rc;
+    }
+    hipGraph_t graph = nullptr;
+    PD_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    rc = pd_decode_fullres(ctx, thre1, thre2);
+    const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != PD_OK || e_end != hipSuccess || graph == nullptr) {
+        if (graph) (void)hipGraphDestroy(graph);
+        ctx->use_graph = 0;  // capture is not possible here: stay eager from now on
+        ctx->prof_n = 0;
+        if (rc != PD_OK) return rc;
+        return pd_decode_fullres(ctx, thre1, thre2);
+    }
+    const hipError_t e_inst = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e_inst != hipSuccess) {
+        ctx->graph_exec = nullptr;
+        ctx->use_graph = 0;
+        ctx->prof_n = 0;
+        return pd_decode_fullres(ctx, thre1, thre2);
+    }
+    ctx->graph_key = key;
+    ctx->graph_res_have = ctx->res_have;
+    ctx->graph_prof_n = ctx->prof_n;
+    PD_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    return PD_OK;
 }
 
 void pd_prof_begin(pd_ctx* ctx, int stage) {
@@ -594,18 +686,14 @@ extern "C" int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = prof_harvest(ctx);
+    if (rc != PD_OK) return rc;
     for (int s = 0; s < PD_N_STAGES; ++s) {
-        if (ms) ms[s] = 0.0;
-        if (launches) launches[s] = 0;
+        if (ms) ms[s] = ctx->prof_ms[s];
+        if (launches) launches[s] = ctx->prof_cnt[s];
+        ctx->prof_ms[s] = 0.0;
+        ctx->prof_cnt[s] = 0;
     }
-    for (int i = 0; i < ctx->prof_n; ++i) {
-        float t = 0.f;
-        PD_HIP(ctx, hipEventElapsedTime(&t, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
-        const int s = ctx->prof_stage[i];
-        if (ms) ms[s] += (double)t;
-        if (launches) launches[s] += 1;
-    }
-    ctx->prof_n = 0;
     return PD_OK;
 }
 

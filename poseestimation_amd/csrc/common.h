@@ -68,6 +68,15 @@ __host__ __device__ inline ResLayout pd_res_layout(int B) {
     return l;
 }
 
+// Everything a captured pd_decode_batch launch sequence depends on.
+struct GraphKey {
+    const float* heat;
+    const float* paf;
+    int B, h, w, H, W;
+    double t1, t2;
+    int mode, impl, prof;
+};
+
 struct TableSlot {
     int32_t* i;
     float* f;
@@ -112,11 +121,15 @@ struct pd_ctx {
     int kf_ok;                       // tables valid for (kf_h, kf_w, kf_H, kf_W)
     int kf_h, kf_w, kf_H, kf_W;
     int32_t* kf_ystart;              // [H] first source row of the 8-tap window
+    int32_t* kf_ystart_host;         // host copy (band geometry is derived from it)
     float* kf_ycoef;                 // [H][8]
     float* kf_xcoef;                 // [ceil(W/8)][10][7]
     size_t kf_ycap, kf_xcap;
     int32_t* cand;                   // [B][18][CK] packed (y << 16 | x)
     int32_t* cand_count;             // [B][18]
+    float* absmax;                   // [B] max |heat| per image
+    float* heat_planar;              // (B, 19, h, w) copy of the network heatmaps
+    size_t heat_planar_cap;
     int cand_cap;                    // CK
     // ---- peaks ----
     RawPeak* raw;        // [B][18][PK] unordered
@@ -145,9 +158,18 @@ struct pd_ctx {
     size_t res_cap, res_spec, res_have;
     int have_peaks, have_conns, have_persons, packed;
     // ---- stage timing (pd_profile) ----
-    int prof_on, prof_n, prof_cap;
+    int prof_on, prof_n, prof_cap;  // prof_n: pairs recorded since the last harvest
     hipEvent_t* prof_ev;  // [2*i] start, [2*i+1] stop
     int* prof_stage;
+    double prof_ms[PD_N_STAGES];
+    int64_t prof_cnt[PD_N_STAGES];
+    // ---- HIP graph of the pd_decode_batch launch sequence ----
+    int use_graph;
+    hipGraphExec_t graph_exec;
+    GraphKey graph_key;   // what graph_exec was captured for
+    GraphKey graph_seen;  // the last call that ran eagerly
+    size_t graph_res_have;
+    int graph_prof_n;
 };
 
 // Record a start / stop event pair around a stage's kernel launch when profiling is on.

@@ -1,10 +1,11 @@
 // Person assembly: multi_person_parse of utils/postprocess.py:163-237 (mode P) and
 // its inlined twin predict.py:179-252 (mode D), plus the packing of all per-image
-// results into contiguous arrays.
+// results into one contiguous buffer.
 //
 // The algorithm is sequential over limbs and, within a limb, over connections in
-// pick order; one wavefront runs it per image with the person table in LDS.  Lanes
-// parallelise the "which persons already hold id_a or id_b" scan and the row moves.
+// pick order; one wavefront runs it per image.  k_parse_wave is the fast form (lane j
+// owns person j, at most 64 open persons); k_parse keeps whole rows in an LDS table of
+// max_persons rows and takes the images the fast form hands over.
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -17,6 +18,7 @@ struct ParseArgs {
     double* persons;
     int32_t* person_count;
     int32_t* status;
+    int only_flagged;  // != 0: only images the fast kernel handed over (count -1)
 };
 
 __global__ void __launch_bounds__(64)
@@ -24,10 +26,13 @@ k_parse(ParseArgs a) {
     extern __shared__ __align__(16) double tab[];  // [max_persons][20]
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
+    if (a.only_flagged && a.person_count[b] != -1) return;
     int n = 0;           // live rows
     int err = PD_OK;
+    // the limb's connection counts, one per lane, fetched once
+    const int my_nc = lane < PD_N_LIMBS ? a.limb_count[b * PD_N_LIMBS + lane] : 0;
     for (int k = 0; k < PD_N_LIMBS; ++k) {
-        const int nc = a.limb_count[b * PD_N_LIMBS + k];
+        const int nc = __builtin_amdgcn_readlane(my_nc, k);
         if (nc <= 0) continue;  // special limb or no connection
         const int pa = pd_limb_from(k), pb = pd_limb_to(k);
         const pd_conn* rows = a.conn + ((size_t)b * PD_N_LIMBS + k) * a.PK;
@@ -120,6 +125,176 @@ k_parse(ParseArgs a) {
     }
 }
 
+// ---- one lane per person -----------------------------------------------------------
+// Lane j owns person j: its score and part count live in that lane's registers and its
+// 18 part ids in LDS as ids[part][j] (int32, exact: ids are small integers and a merge
+// only ever forms -1 + 1 + id).  "Which persons hold id_a or id_b" is two LDS reads per
+// lane and one ballot.  All connections of the image are staged into LDS up front with
+// one round trip to memory.  At most 64 open persons and WAVE_CONNS connections; an
+// image beyond that is handed to k_parse (person_count = -1).
+#define WAVE_CONNS 1024
+
+__device__ __forceinline__ double bcast_d(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64)
+k_parse_wave(ParseArgs a) {
+    __shared__ int ids[PD_N_PARTS][64];
+    __shared__ int c_ida[WAVE_CONNS], c_idb[WAVE_CONNS];
+    __shared__ double c_score[WAVE_CONNS], c_ca[WAVE_CONNS], c_cb[WAVE_CONNS];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int my_nc = lane < PD_N_LIMBS ? max(0, a.limb_count[b * PD_N_LIMBS + lane]) : 0;
+    // exclusive prefix of the connection counts over the limbs
+    int off = my_nc;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const int v = __shfl_up(off, d);
+        if (lane >= d) off += v;
+    }
+    const int total = __builtin_amdgcn_readlane(off, PD_N_LIMBS - 1);
+    off -= my_nc;
+    if (total > WAVE_CONNS) {
+        if (lane == 0) a.person_count[b] = -1;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < PD_N_LIMBS; ++k) {
+        const int nc = __builtin_amdgcn_readlane(my_nc, k), o = __builtin_amdgcn_readlane(off, k);
+        for (int i = lane; i < nc; i += 64) {
+            const pd_conn r = a.conn[((size_t)b * PD_N_LIMBS + k) * a.PK + i];
+            const double* cf = a.conn_conf + (((size_t)b * PD_N_LIMBS + k) * a.PK + i) * 2;
+            c_ida[o + i] = r.id_a;
+            c_idb[o + i] = r.id_b;
+            c_score[o + i] = r.score;
+            c_ca[o + i] = cf[0];
+            c_cb[o + i] = cf[1];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PD_N_PARTS; ++p) ids[p][lane] = -1;
+    __syncthreads();
+    double my_score = 0.0;
+    int my_cnt = 0;
+    int n = 0;
+    int rc = 0;  // 1 = hand over, 2 = mode-D index error
+    for (int k = 0; k < PD_N_LIMBS && rc == 0; ++k) {
+        const int nc = __builtin_amdgcn_readlane(my_nc, k), o = __builtin_amdgcn_readlane(off, k);
+        if (nc == 0) continue;
+        const int pa = pd_limb_from(k), pb = pd_limb_to(k);
+        // the two id columns this limb tests stay in registers for the whole limb; LDS
+        // is written through and only re-read around the (rare) merges
+        int col_a = ids[pa][lane], col_b = ids[pb][lane];
+        for (int c0 = 0; c0 < nc && rc == 0; c0 += 64) {
+            // this chunk's connections, one per lane, broadcast below with readlane
+            const int mine = min(o + c0 + lane, WAVE_CONNS - 1);
+            const int l_ida = c_ida[mine], l_idb = c_idb[mine];
+            const double l_score = c_score[mine], l_ca = c_ca[mine], l_cb = c_cb[mine];
+            const int m_end = min(64, nc - c0);
+            for (int s = 0; s < m_end; ++s) {
+                const int ida = __builtin_amdgcn_readlane(l_ida, s), idb = __builtin_amdgcn_readlane(l_idb, s);
+                const double score = bcast_d(l_score, s), conf_a = bcast_d(l_ca, s), conf_b = bcast_d(l_cb, s);
+                const bool hit = lane < n && (col_a == ida || col_b == idb);
+                const unsigned long long m = __ballot(hit);
+                const int found = __builtin_popcountll(m);
+                if (found == 0) {
+                    if (a.mode == PD_MODE_D || k < 17) {  // utils/postprocess.py:196 / predict.py:228
+                        if (n >= 64 || n >= a.max_persons) {
+                            rc = 1;
+                            break;
+                        }
+                        if (lane == n) {
+                            col_a = ida;
+                            col_b = idb;
+                            ids[pa][lane] = ida;
+                            ids[pb][lane] = idb;
+                            my_score = (conf_a + conf_b) + score;
+                            my_cnt = 2;
+                        }
+                        ++n;
+                    }
+                } else if (found == 1) {
+                    const int j0 = __builtin_ctzll(m);
+                    if (lane == j0 && col_b != idb) {  // :210 / predict.py:205
+                        col_b = idb;
+                        ids[pb][lane] = idb;
+                        my_cnt += 1;
+                        my_score += conf_b + score;
+                    }
+                } else if (found == 2) {
+                    const int j0 = __builtin_ctzll(m), j1 = __builtin_ctzll(m & (m - 1ull));
+                    __syncthreads();  // the table in LDS is complete up to here
+                    const bool both = lane < PD_N_PARTS && ids[lane][j0] >= 0 && ids[lane][j1] >= 0;
+                    const bool overlap = __ballot(both) != 0ull;  // is_isolated, :14-16
+                    if (!overlap) {
+                        // merge person j1 into j0 (:218-222 / predict.py:216-219), delete j1
+                        if (lane < PD_N_PARTS) ids[lane][j0] = (ids[lane][j0] + 1) + ids[lane][j1];
+                        const double s1 = __shfl(my_score, j1);
+                        const int c1 = __shfl(my_cnt, j1);
+                        if (lane == j0) {
+                            my_score = (my_score + s1) + score;
+                            my_cnt += c1;
+                        }
+                        __syncthreads();
+                        // close the gap: persons above j1 move down one lane
+                        int nxt[PD_N_PARTS];
+#pragma unroll
+                        for (int p = 0; p < PD_N_PARTS; ++p) nxt[p] = ids[p][lane < 63 ? lane + 1 : lane];
+                        const double nxs = __shfl_down(my_score, 1);
+                        const int nxc = __shfl_down(my_cnt, 1);
+                        __syncthreads();
+                        if (lane >= j1) {
+#pragma unroll
+                            for (int p = 0; p < PD_N_PARTS; ++p) ids[p][lane] = lane == 63 ? -1 : nxt[p];
+                            my_score = nxs;
+                            my_cnt = nxc;
+                        }
+                        --n;
+                        __syncthreads();
+                        col_a = ids[pa][lane];
+                        col_b = ids[pb][lane];
+                    } else if (lane == j0 && (a.mode == PD_MODE_P || col_b != idb)) {
+                        col_b = idb;  // :210-214 (always) / predict.py:222-225 (if different)
+                        ids[pb][lane] = idb;
+                        my_cnt += 1;
+                        my_score += conf_b + score;
+                    }
+                } else if (a.mode == PD_MODE_D) {
+                    rc = 2;  // predict.py:199 subset_idx[found] with found == 2
+                    break;
+                }
+            }
+        }
+        __syncthreads();  // this limb's writes are visible before the next limb loads its columns
+    }
+    if (rc == 1) {
+        if (lane == 0) a.person_count[b] = -1;  // k_parse redoes this image
+        return;
+    }
+    if (rc == 2) {
+        if (lane == 0) {
+            a.person_count[b] = 0;
+            if (a.status[b] == PD_OK) a.status[b] = PD_E_INDEX;
+        }
+        return;
+    }
+    // prune (:228-232 / predict.py:248-252) and write out in row order
+    bool keep = false;
+    if (lane < n) keep = !((double)my_cnt < 4.0 || my_score / (double)my_cnt < 0.4);
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+        double* out = a.persons + ((size_t)b * a.max_persons + __builtin_popcountll(m & ((1ull << lane) - 1ull))) * 20;
+#pragma unroll
+        for (int p = 0; p < PD_N_PARTS; ++p) out[p] = (double)ids[p][lane];
+        out[18] = my_score;
+        out[19] = (double)my_cnt;
+    }
+    if (lane == 0) a.person_count[b] = __builtin_popcountll(m);
+}
+
 // ---- packing --------------------------------------------------------------------
 struct PackArgs {
     int B, PK, max_persons;
@@ -129,103 +304,110 @@ struct PackArgs {
     const double* pk_score;
     const pd_conn* conn;
     const double* persons;
-    int64_t* pack_off;  // [3][B+1]
-    unsigned char* res; // result buffer: header | count tables | peaks | conns | persons
+    unsigned char* res;  // result buffer: header | count tables | peaks | conns | persons
     ResLayout lay;
 };
 
-// Exclusive prefix sums over the images (one workgroup; B is at most a few thousand).
+// One workgroup per image.  Every workgroup sums the item counts of all images itself
+// (the prefix over the images before it gives its offsets, the sum over all of them the
+// section bases), so no separate scan launch is needed; B is at most a few thousand.
 __global__ void __launch_bounds__(256)
-k_pack_offsets(PackArgs a) {
-    __shared__ long long s_part[3][256];
-    __shared__ int s_bad[256];
-    const int tid = threadIdx.x;
-    const int per = (a.B + 255) / 256;
-    const int lo = tid * per, hi = min(a.B, lo + per);
-    long long acc[3] = {0, 0, 0};
-    int bad = 0x7fffffff;
-    for (int b = lo; b < hi; ++b) {
-        if (a.have_peaks) acc[0] += a.part_base[b * (PD_N_PARTS + 1) + PD_N_PARTS];
-        if (a.have_conns)
-            for (int k = 0; k < PD_N_LIMBS; ++k) acc[1] += max(0, a.limb_count[b * PD_N_LIMBS + k]);
-        if (a.have_persons) acc[2] += a.person_count[b];
-        if (a.status[b] != PD_OK && b < bad) bad = b;
-    }
-    for (int q = 0; q < 3; ++q) s_part[q][tid] = acc[q];
-    s_bad[tid] = bad;
-    __syncthreads();
-    if (tid == 0) {
-        int fb = 0x7fffffff;
-        for (int q = 0; q < 3; ++q) {
-            long long run = 0;
-            for (int t = 0; t < 256; ++t) {
-                const long long v = s_part[q][t];
-                s_part[q][t] = run;
-                run += v;
-            }
-            ((int64_t*)a.res)[1 + q] = run;
-            a.pack_off[q * (a.B + 1) + a.B] = run;
-        }
-        for (int t = 0; t < 256; ++t) fb = min(fb, s_bad[t]);
-        ((int64_t*)a.res)[0] = a.B;
-        ((int64_t*)a.res)[4] = fb == 0x7fffffff ? -1 : fb;
-    }
-    __syncthreads();
-    long long run[3] = {s_part[0][tid], s_part[1][tid], s_part[2][tid]};
-    for (int b = lo; b < hi; ++b) {
-        for (int q = 0; q < 3; ++q) a.pack_off[q * (a.B + 1) + b] = run[q];
-        if (a.have_peaks) run[0] += a.part_base[b * (PD_N_PARTS + 1) + PD_N_PARTS];
-        if (a.have_conns)
-            for (int k = 0; k < PD_N_LIMBS; ++k) run[1] += max(0, a.limb_count[b * PD_N_LIMBS + k]);
-        if (a.have_persons) run[2] += a.person_count[b];
-    }
-}
-
-__global__ void __launch_bounds__(128)
 k_pack(PackArgs a) {
+    __shared__ long long s_red[4][6];
+    __shared__ int s_redbad[4];
+    __shared__ long long s_tot[6];  // prefix (peaks, conns, persons), totals (peaks, conns, persons)
+    __shared__ int s_pbase[PD_N_PARTS + 1], s_lbase[PD_N_LIMBS + 1];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    long long acc[6] = {0, 0, 0, 0, 0, 0};
+    int bad = 0x7fffffff;
+    for (int j = tid; j < a.B; j += 256) {
+        const long long np = a.have_peaks ? a.part_base[j * (PD_N_PARTS + 1) + PD_N_PARTS] : 0;
+        const long long nq = a.have_persons ? a.person_count[j] : 0;
+        acc[3] += np;
+        acc[5] += nq;
+        if (j < b) {
+            acc[0] += np;
+            acc[2] += nq;
+        }
+        if (a.status[j] != PD_OK) bad = min(bad, j);
+    }
+    if (a.have_conns)
+        for (int e = tid; e < a.B * PD_N_LIMBS; e += 256) {
+            const long long nc = max(0, a.limb_count[e]);
+            acc[4] += nc;
+            if (e / PD_N_LIMBS < b) acc[1] += nc;
+        }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[q] += __shfl_xor(acc[q], d);
+        bad = min(bad, __shfl_xor(bad, d));
+    }
+    if ((tid & 63) == 0) {
+        for (int q = 0; q < 6; ++q) s_red[tid >> 6][q] = acc[q];
+        s_redbad[tid >> 6] = bad;
+    }
+    if (tid <= PD_N_PARTS) s_pbase[tid] = a.have_peaks ? a.part_base[b * (PD_N_PARTS + 1) + tid] : 0;
+    __syncthreads();
+    if (tid < 6) s_tot[tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+    if (tid == 6) {
+        int run = 0;
+        for (int k = 0; k < PD_N_LIMBS; ++k) {
+            s_lbase[k] = run;
+            run += a.have_conns ? max(0, a.limb_count[b * PD_N_LIMBS + k]) : 0;
+        }
+        s_lbase[PD_N_LIMBS] = run;
+    }
+    __syncthreads();
+    if (b == 0 && tid == 0) {
+        int64_t* head = (int64_t*)a.res;
+        const int fb = min(min(s_redbad[0], s_redbad[1]), min(s_redbad[2], s_redbad[3]));
+        head[0] = a.B;
+        head[1] = s_tot[3];
+        head[2] = s_tot[4];
+        head[3] = s_tot[5];
+        head[4] = fb == 0x7fffffff ? -1 : fb;
+    }
     // count tables of this image
-    if (tid < PD_N_PARTS) ((int32_t*)(a.res + a.lay.off_part))[b * PD_N_PARTS + tid] = a.have_peaks ? a.part_count[b * PD_N_PARTS + tid] : 0;
-    if (tid < PD_N_LIMBS) ((int32_t*)(a.res + a.lay.off_limb))[b * PD_N_LIMBS + tid] = a.have_conns ? a.limb_count[b * PD_N_LIMBS + tid] : 0;
+    if (tid < PD_N_PARTS)
+        ((int32_t*)(a.res + a.lay.off_part))[b * PD_N_PARTS + tid] = a.have_peaks ? a.part_count[b * PD_N_PARTS + tid] : 0;
+    if (tid < PD_N_LIMBS)
+        ((int32_t*)(a.res + a.lay.off_limb))[b * PD_N_LIMBS + tid] = a.have_conns ? a.limb_count[b * PD_N_LIMBS + tid] : 0;
     if (tid == 0) {
         ((int32_t*)(a.res + a.lay.off_pers))[b] = a.have_persons ? a.person_count[b] : 0;
         ((int32_t*)(a.res + a.lay.off_stat))[b] = a.status[b];
     }
-    const int64_t n_peaks = a.pack_off[a.B], n_conns = a.pack_off[(a.B + 1) + a.B];
-    pd_peak* out_peaks = (pd_peak*)(a.res + a.lay.off_payload);
-    pd_conn* out_conns = (pd_conn*)(a.res + a.lay.off_payload + n_peaks * sizeof(pd_peak));
-    double* out_persons = (double*)(a.res + a.lay.off_payload + n_peaks * sizeof(pd_peak) + n_conns * sizeof(pd_conn));
+    const long long n_peaks = s_tot[3], n_conns = s_tot[4];
+    pd_peak* out_peaks = (pd_peak*)(a.res + a.lay.off_payload) + s_tot[0];
+    pd_conn* out_conns = (pd_conn*)(a.res + a.lay.off_payload + n_peaks * sizeof(pd_peak)) + s_tot[1];
+    double* out_persons = (double*)(a.res + a.lay.off_payload + n_peaks * sizeof(pd_peak) + n_conns * sizeof(pd_conn)) +
+                          s_tot[2] * 20;
     if (a.have_peaks) {
-        pd_peak* out = out_peaks + a.pack_off[b];
-        for (int p = 0; p < PD_N_PARTS; ++p) {
-            const int n = a.part_count[b * PD_N_PARTS + p];
-            const int base = a.part_base[b * (PD_N_PARTS + 1) + p];
-            const size_t o = ((size_t)b * PD_N_PARTS + p) * a.PK;
-            for (int i = tid; i < n; i += blockDim.x) {
-                pd_peak q;
-                q.y = a.pk_y[o + i];
-                q.x = a.pk_x[o + i];
-                q.score = a.pk_score[o + i];
-                out[base + i] = q;
-            }
+        const int n = s_pbase[PD_N_PARTS];
+        for (int i = tid; i < n; i += 256) {
+            int p = 0;
+            while (i >= s_pbase[p + 1]) ++p;
+            const size_t o = ((size_t)b * PD_N_PARTS + p) * a.PK + (i - s_pbase[p]);
+            pd_peak q;
+            q.y = a.pk_y[o];
+            q.x = a.pk_x[o];
+            q.score = a.pk_score[o];
+            out_peaks[i] = q;
         }
     }
     if (a.have_conns) {
-        pd_conn* out = out_conns + a.pack_off[(a.B + 1) + b];
-        int run = 0;
-        for (int k = 0; k < PD_N_LIMBS; ++k) {
-            const int n = max(0, a.limb_count[b * PD_N_LIMBS + k]);
-            const pd_conn* rows = a.conn + ((size_t)b * PD_N_LIMBS + k) * a.PK;
-            for (int i = tid; i < n; i += blockDim.x) out[run + i] = rows[i];
-            run += n;
+        const int n = s_lbase[PD_N_LIMBS];
+        for (int i = tid; i < n; i += 256) {
+            int k = 0;
+            while (i >= s_lbase[k + 1]) ++k;
+            out_conns[i] = a.conn[((size_t)b * PD_N_LIMBS + k) * a.PK + (i - s_lbase[k])];
         }
     }
     if (a.have_persons) {
-        double* out = out_persons + a.pack_off[2 * (a.B + 1) + b] * 20;
         const int n = a.person_count[b] * 20;
         const double* src = a.persons + (size_t)b * a.max_persons * 20;
-        for (int i = tid; i < n; i += blockDim.x) out[i] = src[i];
+        for (int i = tid; i < n; i += 256) out_persons[i] = src[i];
     }
 }
 
@@ -242,7 +424,15 @@ int pd_launch_parse(pd_ctx* ctx) {
     a.status = ctx->status;
     const size_t lds = (size_t)a.max_persons * 20 * sizeof(double);
     pd_prof_begin(ctx, PD_STAGE_PARSE);
-    hipLaunchKernelGGL(k_parse, dim3(ctx->B), dim3(64), lds, ctx->stream, a);
+    if (ctx->impl == PD_IMPL_SIMPLE) {
+        a.only_flagged = 0;
+        hipLaunchKernelGGL(k_parse, dim3(ctx->B), dim3(64), lds, ctx->stream, a);
+    } else {
+        // one lane per person; images with more than 64 open persons fall through to the table kernel
+        a.only_flagged = 1;
+        hipLaunchKernelGGL(k_parse_wave, dim3(ctx->B), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_parse, dim3(ctx->B), dim3(64), lds, ctx->stream, a);
+    }
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
@@ -266,12 +456,10 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.pk_score = ctx->pk_score;
     a.conn = ctx->conn;
     a.persons = ctx->persons;
-    a.pack_off = ctx->pack_off;
     a.res = ctx->res_dev;
     a.lay = pd_res_layout(ctx->B);
     pd_prof_begin(ctx, PD_STAGE_PACK);
-    hipLaunchKernelGGL(k_pack_offsets, dim3(1), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(128), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;

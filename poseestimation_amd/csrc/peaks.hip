@@ -5,8 +5,12 @@
 
 #pragma clang fp contract(off)
 
-// One workgroup per image.  Each part's list is ranked by the unique key y*W + x.
-__global__ void __launch_bounds__(256)
+#define SORT_WAVES 9  // each wavefront orders parts w and w + 9
+
+// One workgroup per image, one wavefront per part.  A part's peaks sit one per lane
+// (64 at a time); the rank of a peak is the number of peaks with a smaller key
+// y*W + x (keys are unique), counted by broadcasting every key across the wave.
+__global__ void __launch_bounds__(SORT_WAVES * 64)
 k_sort_peaks(const RawPeak* __restrict__ raw, const int32_t* __restrict__ raw_count, int PK, int W,
              int max_pairs, int32_t* pk_y, int32_t* pk_x, int32_t* pk_id, double* pk_score,
              int32_t* part_count, int32_t* part_base, int32_t* pair_off, int32_t* status) {
@@ -15,6 +19,7 @@ k_sort_peaks(const RawPeak* __restrict__ raw, const int32_t* __restrict__ raw_co
     __shared__ int s_over;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     if (tid == 0) s_over = 0;
     __syncthreads();
     if (tid < PD_N_PARTS) {
@@ -46,34 +51,48 @@ k_sort_peaks(const RawPeak* __restrict__ raw, const int32_t* __restrict__ raw_co
             }
         }
         pair_off[b * (PD_N_LIMBS + 1) + PD_N_LIMBS] = pairs_over ? -1 : (int32_t)pairs;
+        status[b] = s_over ? PD_E_OVERFLOW : PD_OK;
     }
     __syncthreads();
     if (tid < PD_N_PARTS) part_count[b * PD_N_PARTS + tid] = s_cnt[tid];
     if (tid <= PD_N_PARTS) part_base[b * (PD_N_PARTS + 1) + tid] = s_base[tid];
-    if (tid == 0) status[b] = s_over ? PD_E_OVERFLOW : PD_OK;
-    for (int p = 0; p < PD_N_PARTS; ++p) {
+    for (int p = wave; p < PD_N_PARTS; p += SORT_WAVES) {
         const int n = s_cnt[p];
         const RawPeak* list = raw + ((size_t)b * PD_N_PARTS + p) * PK;
         const size_t o = ((size_t)b * PD_N_PARTS + p) * PK;
-        for (int i = tid; i < n; i += blockDim.x) {
-            const RawPeak me = list[i];
-            const long long key = (long long)me.y * W + me.x;
+        const int base = s_base[p];
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int i = c0 + lane;
+            RawPeak me;
+            me.y = 0;
+            me.x = 0;
+            me.score = 0.0;
+            if (i < n) me = list[i];
+            const int key = me.y * W + me.x;  // H * W < 2^31
             int rank = 0;
-            for (int j = 0; j < n; ++j) {
-                const RawPeak o2 = list[j];
-                rank += ((long long)o2.y * W + o2.x) < key;
+            for (int d0 = 0; d0 < n; d0 += 64) {
+                const int j = d0 + lane;
+                int other = 0x7fffffff;
+                if (j < n) {
+                    const RawPeak q = list[j];
+                    other = q.y * W + q.x;
+                }
+                const int m = min(64, n - d0);
+                for (int s = 0; s < m; ++s) rank += __shfl(other, s) < key;
             }
-            pk_y[o + rank] = me.y;
-            pk_x[o + rank] = me.x;
-            pk_score[o + rank] = me.score;
-            pk_id[o + rank] = s_base[p] + rank;
+            if (i < n) {
+                pk_y[o + rank] = me.y;
+                pk_x[o + rank] = me.x;
+                pk_score[o + rank] = me.score;
+                pk_id[o + rank] = base + rank;
+            }
         }
     }
 }
 
 int pd_launch_sort_peaks(pd_ctx* ctx) {
     pd_prof_begin(ctx, PD_STAGE_SORT);
-    hipLaunchKernelGGL(k_sort_peaks, dim3(ctx->B), dim3(256), 0, ctx->stream, ctx->raw, ctx->raw_count,
+    hipLaunchKernelGGL(k_sort_peaks, dim3(ctx->B), dim3(SORT_WAVES * 64), 0, ctx->stream, ctx->raw, ctx->raw_count,
                        ctx->cfg.max_peaks_per_part, ctx->W, ctx->cfg.max_pairs_per_image, ctx->pk_y, ctx->pk_x,
                        ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off, ctx->status);
     pd_prof_end(ctx);

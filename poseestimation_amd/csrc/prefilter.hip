@@ -9,7 +9,7 @@
 //     S~[Y][X] = sum_p Kx[X][p] * T[Y][t0(X)+p]            (columns)
 // in float32 with fused multiply-adds.  Against the exact float64 value S of the
 // reference (which is computed from the float32-rounded bicubic map),
-//     |S~ - S| <= 53 * 2^-24 * 1.89 * M  <  eps := 2^-17 * M,   M = max |src| of the plane
+//     |S~ - S| <= 53 * 2^-24 * 1.89 * M  <  eps := 2^-17 * M,   M >= max |src| of the plane
 // (coefficient rounding, 8-term chains on both axes, and the rounding inside the
 // reference's own float32 bicubic; sum_k |K| <= 1.375 per axis).  A pixel can only be
 // a peak (S > thr, S >= each in-image neighbour, S >= 0 for out-of-image ones) if
@@ -21,6 +21,7 @@
 // 5 x-pass sums) and the exact test decides.  Planes with more candidates than the list
 // holds (plateaus) are redone by the exact streaming kernel.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -28,8 +29,9 @@
 
 #pragma clang fp contract(off)
 
-#define KF_RB 16       // rows per thread in the column pass
 #define KF_NT 256
+#define KF_MAX_BANDS 32
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 static const double h_gw[PD_GTAPS] = PD_GAUSS_WEIGHTS;
 
@@ -99,7 +101,7 @@ static int build_filter_tables(pd_ctx* ctx) {
                 const double v = Kx[(size_t)X * w + t];
                 if (v == 0.0) continue;
                 if (t < t_lo || t > t_lo + 6) return PD_E_STATE;
-                xcoef[((size_t)g * 10 + jj) * 7 + (t - t_lo)] = (float)v;
+                xcoef[((size_t)jj * 7 + (t - t_lo)) * wg + g] = (float)v;  // [70][wg]: lane g reads coalesced
             }
         }
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -120,6 +122,12 @@ static int build_filter_tables(pd_ctx* ctx) {
         PD_HIP(ctx, hipMalloc(&ctx->kf_xcoef, sizeof(float) * 70 * wg));
         ctx->kf_xcap = wg;
     }
+    {
+        int32_t* hcopy = (int32_t*)realloc(ctx->kf_ystart_host, sizeof(int32_t) * H);
+        if (!hcopy) return PD_E_STATE;
+        memcpy(hcopy, ystart.data(), sizeof(int32_t) * H);
+        ctx->kf_ystart_host = hcopy;
+    }
     PD_HIP(ctx, hipMemcpy(ctx->kf_ystart, ystart.data(), sizeof(int32_t) * H, hipMemcpyHostToDevice));
     PD_HIP(ctx, hipMemcpy(ctx->kf_ycoef, ycoef.data(), sizeof(float) * 8 * H, hipMemcpyHostToDevice));
     PD_HIP(ctx, hipMemcpy(ctx->kf_xcoef, xcoef.data(), sizeof(float) * 70 * wg, hipMemcpyHostToDevice));
@@ -127,86 +135,148 @@ static int build_filter_tables(pd_ctx* ctx) {
     return PD_OK;
 }
 
+// (B, h, w, 19) -> planar (B, 19, h, w) through LDS so that both sides are coalesced,
+// and max |value| over all 19 channels of each image (an upper bound of every plane's
+// maximum, which is all the tolerance needs; non-negative floats order like their bit
+// patterns, so the maximum is taken with an integer atomic).
+#define KP_PIX 256
+__global__ void __launch_bounds__(256)
+k_heat_planar(const float* __restrict__ lo, int npix, float* __restrict__ planar, unsigned int* __restrict__ absmax_bits) {
+    __shared__ float tile[KP_PIX * PD_CH_HEAT];
+    __shared__ float s_red[4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int p0 = blockIdx.x * KP_PIX;
+    const int np = min(KP_PIX, npix - p0);
+    const float* src = lo + ((size_t)b * npix + p0) * PD_CH_HEAT;
+    float m = 0.f;
+    for (int i = tid; i < np * PD_CH_HEAT; i += 256) {
+        const float v = src[i];
+        tile[i] = v;
+        m = fmaxf(m, fabsf(v));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((tid & 63) == 0) s_red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0)
+        atomicMax(absmax_bits + b, __float_as_uint(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]))));
+    float* dst = planar + (size_t)b * PD_CH_HEAT * npix + p0;
+    for (int c = 0; c < PD_CH_HEAT; ++c)
+        for (int i = tid; i < np; i += 256) dst[(size_t)c * npix + i] = tile[i * PD_CH_HEAT + c];
+}
+
 struct FilterArgs {
-    const float* lo;  // (B, h, w, 19)
+    const float* lo;  // planar copy (B, 19, h, w)
     int h, w, H, W, wg;
-    int RL, BH, src_rows;  // row lanes, band height, source rows staged per band
+    int RL, RB, BH, src_rows;  // row lanes, rows per lane, band height, source rows staged per band
     const int32_t* ystart;
     const float* ycoef;
     const float* xcoef;
+    const float* absmax;  // [B]
     double thr;
     int32_t* cand;
     int32_t* cand_count;
     int CK;
+    int dbg;  // timing experiments only (PD_KF_DEBUG): 1 = stop before the column pass
+    int band_sb0[KF_MAX_BANDS];  // first source row staged for each band
+    int band_ns[KF_MAX_BANDS];   // number of source rows staged
 };
 
 // One workgroup per (row band, part, image).
 __global__ void __launch_bounds__(KF_NT)
 k_prefilter(FilterArgs a) {
     extern __shared__ __align__(16) float lds[];
-    __shared__ float s_red[KF_NT / 64];
     const int tid = threadIdx.x;
     const int band = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
     const int h = a.h, w = a.w, H = a.H, W = a.W;
     const int Yb = band * a.BH;               // first row this band decides
     const int nrowsT = a.BH + 2;              // rows Yb-1 .. Yb+BH
     const int tw = w + 8;                     // T row: 4 zero pads each side
-    float* srcL = lds;                        // [src_rows][w]
-    float* T = lds + (size_t)a.src_rows * w;  // [BH+2][w+8]
-    const float* img = a.lo + (size_t)b * h * w * PD_CH_HEAT + part;
+    float* kcL = lds;                                     // [BH+2][8] row-pass coefficients
+    int* ysL = (int*)(lds + (size_t)nrowsT * 8);          // [BH+2] window starts (relative)
+    float* srcL = lds + (size_t)nrowsT * 9;               // [src_rows + 8][w]
+    float* T = srcL + (size_t)(a.src_rows + 8) * w;       // [BH+2][w+8]
+    const float* img = a.lo + ((size_t)b * PD_CH_HEAT + part) * h * w;  // planar (B, 19, h, w)
 
-    // M = max |src| of the plane
-    float m = 0.f;
-    for (int i = tid; i < h * w; i += KF_NT) m = fmaxf(m, fabsf(img[(size_t)i * PD_CH_HEAT]));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((tid & 63) == 0) s_red[tid >> 6] = m;
-
-    // source rows of this band
-    const int Ylo = Yb - 1 < 0 ? 0 : Yb - 1;
-    const int Yhi = Yb + a.BH > H - 1 ? H - 1 : Yb + a.BH;
-    const int sb0 = a.ystart[Ylo];
-    const int sb1 = min(h - 1, a.ystart[Yhi] + 7);
-    const int ns = min(sb1 - sb0 + 1, a.src_rows);
-    for (int i = tid; i < ns * w; i += KF_NT) srcL[i] = img[((size_t)(sb0 + i / w) * w + i % w) * PD_CH_HEAT];
+    // Everything this band reads from memory is requested at once: its source rows,
+    // and the row-pass coefficients and window starts of its BH + 2 rows (contiguous in
+    // the tables), so the row pass below runs out of LDS with no dependent loads.
+    const int sb0 = a.band_sb0[band], ns = a.band_ns[band];
+    for (int i = tid; i < ns * w; i += KF_NT) srcL[i] = img[(size_t)sb0 * w + i];
+    for (int i = tid; i < 8 * w; i += KF_NT) srcL[ns * w + i] = 0.f;  // rows past the range meet zero coefficients
+    for (int i = tid; i < nrowsT * 8; i += KF_NT) {
+        const int Y = Yb - 1 + (i >> 3);
+        kcL[i] = (Y >= 0 && Y < H) ? a.ycoef[8 * (size_t)Y + (i & 7)] : 0.f;
+    }
+    for (int i = tid; i < nrowsT; i += KF_NT) {
+        const int Y = Yb - 1 + i;
+        ysL[i] = (Y >= 0 && Y < H) ? a.ystart[Y] - sb0 : 0;
+    }
     __syncthreads();
-    float M = s_red[0];
-#pragma unroll
-    for (int i = 1; i < KF_NT / 64; ++i) M = fmaxf(M, s_red[i]);
+    if (a.dbg == 2) return;
 
-    // rows: T[Yr][t], Yr = Y - (Yb - 1)
-    for (int i = tid; i < nrowsT * tw; i += KF_NT) {
-        const int Yr = i / tw, tt = i - Yr * tw;
-        const int Y = Yb - 1 + Yr, t = tt - 4;
-        float v = 0.f;
-        if (Y >= 0 && Y < H && t >= 0 && t < w) {
-            const float* kc = a.ycoef + 8 * (size_t)Y;
-            const float* sp = srcL + (size_t)(a.ystart[Y] - sb0) * w + t;
-            v = kc[0] * sp[0];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                // rows past the staged range only ever meet a zero coefficient
-                const int rr = a.ystart[Y] - sb0 + k;
-                const float sv = rr < ns ? sp[(size_t)k * w] : 0.f;
-                v = fmaf(kc[k], sv, v);
+    // rows: T[Yr][t], Yr = Y - (Yb - 1).  A thread owns one source column t and a run
+    // of consecutive rows: the eight source values of its window stay in registers and
+    // are re-read only when the window start moves (once per 8 rows)
+    for (int i = tid; i < nrowsT * 8; i += KF_NT) {  // zero pads left and right of each T row
+        const int r = i >> 3, p = i & 7;
+        T[(size_t)r * tw + (p < 4 ? p : w + p)] = 0.f;
+    }
+    {
+        const int n_chunks = KF_NT / w;  // w <= 256 is guaranteed by the table builder
+        const int col = tid % w, chunk = tid / w;
+        if (chunk < n_chunks) {
+            const int per = (nrowsT + n_chunks - 1) / n_chunks;
+            const int r_lo = chunk * per, r_hi = min(nrowsT, r_lo + per);
+            int cur = -1;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+            for (int r = r_lo; r < r_hi; ++r) {
+                const int y0 = ysL[r];
+                if (y0 != cur) {
+                    const float* sp = srcL + (size_t)y0 * w + col;
+                    s0 = sp[0];
+                    s1 = sp[w];
+                    s2 = sp[2 * w];
+                    s3 = sp[3 * w];
+                    s4 = sp[4 * w];
+                    s5 = sp[5 * w];
+                    s6 = sp[6 * w];
+                    s7 = sp[7 * w];
+                    cur = y0;
+                }
+                const float4 ka = *(const float4*)(kcL + 8 * r), kb = *(const float4*)(kcL + 8 * r + 4);
+                float v = ka.x * s0;
+                v = fmaf(ka.y, s1, v);
+                v = fmaf(ka.z, s2, v);
+                v = fmaf(ka.w, s3, v);
+                v = fmaf(kb.x, s4, v);
+                v = fmaf(kb.y, s5, v);
+                v = fmaf(kb.z, s6, v);
+                v = fmaf(kb.w, s7, v);
+                T[(size_t)r * tw + col + 4] = v;  // rows outside the image have zero coefficients: T = 0
             }
         }
-        T[i] = v;
     }
     __syncthreads();
 
     // columns + tolerant NMS: thread = (column group g, row lane rl)
     const int g = tid % a.wg, rl = tid / a.wg;
-    if (rl >= a.RL) return;
-    float kx[10][7];
-    {
-        const float* kp = a.xcoef + (size_t)g * 70;
+    if (rl >= a.RL || a.dbg == 1) return;
+    // coefficients: the eight real columns as four pairs for packed FMAs (all use
+    // window positions 1..7), the two halo columns (positions 0..6 and 2..8) scalar
+    float2v kp[4][7];
+    float kl[7], kr[7];
 #pragma unroll
-        for (int jj = 0; jj < 10; ++jj)
+    for (int p = 0; p < 7; ++p) {
+        kl[p] = a.xcoef[(size_t)(0 * 7 + p) * a.wg + g];
+        kr[p] = a.xcoef[(size_t)(9 * 7 + p) * a.wg + g];
 #pragma unroll
-            for (int p = 0; p < 7; ++p) kx[jj][p] = kp[jj * 7 + p];
+        for (int q = 0; q < 4; ++q) {
+            kp[q][p].x = a.xcoef[(size_t)((2 * q + 1) * 7 + p) * a.wg + g];
+            kp[q][p].y = a.xcoef[(size_t)((2 * q + 2) * 7 + p) * a.wg + g];
+        }
     }
-    const double eps = ldexp((double)M, -17);
+    const double eps = ldexp((double)a.absmax[b], -17);
     const float thr_lo = nextafterf((float)(a.thr - eps), -INFINITY);
     const float e2 = nextafterf((float)(2.0 * eps), INFINITY);
     float prev1[10], prev2[8];
@@ -214,35 +284,80 @@ k_prefilter(FilterArgs a) {
     for (int j = 0; j < 10; ++j) prev1[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) prev2[j] = 0.f;
-    const int Y0 = Yb + rl * KF_RB;  // first row this thread decides
+    const int Y0 = Yb + rl * a.RB;  // first row this thread decides
     int32_t* plane_count = a.cand_count + b * PD_N_PARTS + part;
     int32_t* plane_list = a.cand + ((size_t)b * PD_N_PARTS + part) * a.CK;
-    for (int it = 0; it < KF_RB + 2; ++it) {
+    for (int it = 0; it < a.RB + 2; ++it) {
         const int Y = Y0 - 1 + it;  // row being evaluated; row Y - 1 is decided
         const float* tp = T + (size_t)(Y - (Yb - 1)) * tw + g;
         float t[9];
 #pragma unroll
         for (int p = 0; p < 9; ++p) t[p] = tp[p];
         float cur[10];
+        // |S~| <= 1.375 * max |T| over the window (sum of |Kx| per column <= 1.375): where
+        // that is below the threshold for the whole wavefront the ten sums are skipped and
+        // zeros stand in -- such pixels cannot be candidates, and as neighbours of a
+        // candidate (which is > thr_lo > 0) a zero passes exactly when the true value would
+        float tmax = fabsf(t[0]);
 #pragma unroll
-        for (int jj = 0; jj < 10; ++jj) {
-            const int p0 = jj == 0 ? 0 : (jj == 9 ? 2 : 1);
-            float v = kx[jj][0] * t[p0];
+        for (int p = 1; p < 9; ++p) tmax = fmaxf(tmax, fabsf(t[p]));
+        if (__ballot(1.376f * tmax >= thr_lo) == 0ull) {
 #pragma unroll
-            for (int p = 1; p < 7; ++p) v = fmaf(kx[jj][p], t[p0 + p], v);
-            cur[jj] = v;
+            for (int j = 0; j < 10; ++j) cur[j] = 0.f;
+        } else {
+            float2v acc[4];
+            float hl = kl[0] * t[0], hr = kr[0] * t[2];
+            {
+                const float2v tt = {t[1], t[1]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = kp[q][0] * tt;
+            }
+#pragma unroll
+            for (int p = 1; p < 7; ++p) {
+                const float2v tt = {t[1 + p], t[1 + p]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_elementwise_fma(kp[q][p], tt, acc[q]);
+                hl = fmaf(kl[p], t[p], hl);
+                hr = fmaf(kr[p], t[2 + p], hr);
+            }
+            cur[0] = hl;
+            cur[9] = hr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cur[2 * q + 1] = acc[q].x;
+                cur[2 * q + 2] = acc[q].y;
+            }
         }
         const int Yc = Y - 1;
         if (it >= 2 && Yc < H) {
+            // most rows hold nothing above the threshold: one max + ballot skips them
+            float mx = prev1[1];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float c = prev1[j + 1];
-                const int X = 8 * g + j;
-                const bool ok = X < W && c > thr_lo && c >= prev2[j] - e2 && c >= cur[j + 1] - e2 &&
-                                c >= prev1[j] - e2 && c >= prev1[j + 2] - e2;
-                if (ok) {
-                    const int pos = atomicAdd(plane_count, 1);
-                    if (pos < a.CK) plane_list[pos] = (Yc << 16) | X;
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, prev1[j + 1]);
+            if (__ballot(mx > thr_lo) != 0ull) {
+                // branch-free test of the eight pixels: q >= 0 iff the pixel passes
+                // (c >= n - e2 is tested as c + e2 >= n; the half-ulp rounding of that sum,
+                // 6e-8 |c|, is far inside the slack between eps and the error bound)
+                float best = -1.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float c = prev1[j + 1];
+                    const float m4 = fmaxf(fmaxf(prev2[j], cur[j + 1]), fmaxf(prev1[j], prev1[j + 2]));
+                    best = fmaxf(best, fminf(c - thr_lo, (c + e2) - m4));
+                }
+                if (best >= 0.f) {  // rare: some pixel of this thread's eight may be a candidate
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float c = prev1[j + 1];
+                        const float ce = c + e2;
+                        const int X = 8 * g + j;
+                        const bool ok = X < W && c > thr_lo && ce >= prev2[j] && ce >= cur[j + 1] &&
+                                        ce >= prev1[j] && ce >= prev1[j + 2];
+                        if (ok) {
+                            const int pos = atomicAdd(plane_count, 1);
+                            if (pos < a.CK) plane_list[pos] = (Yc << 16) | X;
+                        }
+                    }
                 }
             }
         }
@@ -265,31 +380,62 @@ struct VerifyArgs {
 };
 
 // One workgroup per (part, image); 32 lanes per candidate, 8 candidates per pass.
-__global__ void __launch_bounds__(256)
+// Lane l < 27 owns column X + l - 13: it loads the (at most 8) source rows the 27
+// bicubic rows Y-13 .. Y+13 draw on, forms their horizontal 4-tap sums once, then the
+// 27 vertical sums and the three y-pass sums; five lanes finish the x pass.
+__global__ void __launch_bounds__(256, 2)
 k_verify(VerifyArgs a) {
     __shared__ double ypL[8][3][28];
+    __shared__ float hvL[8][256];
     const int part = blockIdx.x, b = blockIdx.y;
     const int plane = b * PD_N_PARTS + part;
     const int n = a.cand_count[plane];
     if (n <= 0 || n > a.CK) return;  // overflowing planes are redone by the exact kernel
     const int tid = threadIdx.x;
     const int half = tid >> 5, l = tid & 31;
-    const int H = a.src.H, W = a.src.W;
+    const int H = a.src.H, W = a.src.W, h = a.src.h, w = a.src.w, C = a.src.C;
     const int32_t* list = a.cand + (size_t)plane * a.CK;
+    const float* img = a.src.lo + (size_t)b * h * w * C + part;
     for (int base = 0; base < n; base += 8) {
         const int ci = base + half;
         const bool active = ci < n;
         int Y = 0, X = 0;
         double u13 = 0.0;
-        if (active && l < 27) {
+        if (active) {
             const int packed = list[ci];
             Y = packed >> 16;
             X = packed & 0xffff;
-            ColLoader<PD_SRC_LOWRES> ld;
-            ld.init(a.src, b, part, pd_reflect(X + l - 13, W));
+        }
+        if (active && l < 27) {
+            // source-row range of the 27 (reflected) rows
+            int rmin = H, rmax = 0;
+#pragma unroll
+            for (int i = 0; i < 27; ++i) {
+                const int r = pd_reflect(Y - 13 + i, H);
+                rmin = min(rmin, r);
+                rmax = max(rmax, r);
+            }
+            const int ymin = a.src.ty.ofs[rmin];
+            const int col = pd_reflect(X + l - 13, W);
+            const int x0 = a.src.tx.ofs[col];
+            const float4 ac = *(const float4*)(a.src.tx.coef + 4 * (size_t)col);
+            const size_t xi0 = (size_t)pd_clampi(x0, 0, w - 1) * C, xi1 = (size_t)pd_clampi(x0 + 1, 0, w - 1) * C,
+                         xi2 = (size_t)pd_clampi(x0 + 2, 0, w - 1) * C, xi3 = (size_t)pd_clampi(x0 + 3, 0, w - 1) * C;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float* row = img + ((size_t)pd_clampi(ymin + q, 0, h - 1) * w) * C;
+                hvL[q][tid] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
+            }
             double u[27];
 #pragma unroll
-            for (int i = 0; i < 27; ++i) u[i] = ld.load(pd_reflect(Y - 13 + i, H));
+            for (int i = 0; i < 27; ++i) {
+                const int r = pd_reflect(Y - 13 + i, H);
+                const int d = min(a.src.ty.ofs[r] - ymin, 4);
+                const float4 bc = *(const float4*)(a.src.ty.coef + 4 * (size_t)r);
+                const float v = ((hvL[d][tid] * bc.x + hvL[d + 1][tid] * bc.y) + hvL[d + 2][tid] * bc.z) +
+                                hvL[d + 3][tid] * bc.w;
+                u[i] = (double)v;
+            }
             u13 = u[13];
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
@@ -299,10 +445,6 @@ k_verify(VerifyArgs a) {
                 for (int d = 12; d >= 1; --d) t += (u[c - d] + u[c + d]) * c_gw[12 - d];
                 ypL[half][e][l] = t;
             }
-        } else if (active) {
-            const int packed = list[ci];
-            Y = packed >> 16;
-            X = packed & 0xffff;
         }
         __syncthreads();
         double S = 0.0;
@@ -348,37 +490,94 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->cand) PD_HIP(ctx, hipFree(ctx->cand));
         if (ctx->cand_count) PD_HIP(ctx, hipFree(ctx->cand_count));
+        if (ctx->absmax) PD_HIP(ctx, hipFree(ctx->absmax));
         ctx->cand = nullptr;
         ctx->cand_count = nullptr;
+        ctx->absmax = nullptr;
         PD_HIP(ctx, hipMalloc(&ctx->cand, sizeof(int32_t) * (size_t)ctx->cfg.max_batch * PD_N_PARTS * CK));
         PD_HIP(ctx, hipMalloc(&ctx->cand_count, sizeof(int32_t) * (size_t)ctx->cfg.max_batch * PD_N_PARTS));
+        PD_HIP(ctx, hipMalloc(&ctx->absmax, sizeof(float) * (size_t)ctx->cfg.max_batch));
         ctx->cand_cap = CK;
     }
-    PD_HIP(ctx, hipMemsetAsync(ctx->cand_count, 0, sizeof(int32_t) * B * PD_N_PARTS, ctx->stream));
+    {
+        const size_t need = sizeof(float) * (size_t)B * PD_CH_HEAT * h * w;
+        if (ctx->heat_planar_cap < need) {
+            PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->heat_planar) PD_HIP(ctx, hipFree(ctx->heat_planar));
+            ctx->heat_planar = nullptr;
+            ctx->heat_planar_cap = 0;
+            PD_HIP(ctx, hipMalloc(&ctx->heat_planar, need));
+            ctx->heat_planar_cap = need;
+        }
+    }
     FilterArgs f;
-    f.lo = ctx->lo_heat;
+    f.lo = ctx->heat_planar;
     f.h = h;
     f.w = w;
     f.H = H;
     f.W = W;
     f.wg = (W + 7) / 8;
     f.RL = KF_NT / f.wg;
-    const int rows_needed = (H + KF_RB - 1) / KF_RB;
-    if (f.RL > rows_needed) f.RL = rows_needed;
-    f.BH = f.RL * KF_RB;
-    f.src_rows = (f.BH + 2 + 24) / 8 + 9;
+    // rows per thread: the choice that wastes the fewest row evaluations (each thread
+    // evaluates RB + 2 rows, bands are RL * RB rows) within the LDS budget
+    int best_rb = 0;
+    long best_cost = 0;
+    for (int rb = 8; rb <= 64; ++rb) {
+        const int bh = f.RL * rb;
+        const long lds_b = 4L * ((long)(bh + 2) * 9 + ((bh + 26) / 8 + 17) * w + (long)(bh + 2) * (w + 8));
+        if (lds_b > 40000) break;
+        const long cost = (long)((H + bh - 1) / bh) * f.RL * (rb + 2);
+        if (best_rb == 0 || cost < best_cost) {
+            best_rb = rb;
+            best_cost = cost;
+        }
+    }
+    if (best_rb == 0) return PD_E_STATE;
+    f.RB = best_rb;
+    f.BH = f.RL * f.RB;
+    f.src_rows = (f.BH + 26) / 8 + 9;
     if (f.src_rows > h) f.src_rows = h;
     f.ystart = ctx->kf_ystart;
     f.ycoef = ctx->kf_ycoef;
     f.xcoef = ctx->kf_xcoef;
+    f.absmax = ctx->absmax;
     f.thr = thr;
     f.cand = ctx->cand;
     f.cand_count = ctx->cand_count;
     f.CK = CK;
+    {
+        const char* e = getenv("PD_KF_DEBUG");
+        f.dbg = e ? atoi(e) : 0;
+        const char* r = getenv("PD_KF_RB");
+        if (r && atoi(r) >= 8) {
+            f.RB = atoi(r);
+            f.BH = f.RL * f.RB;
+            f.src_rows = (f.BH + 26) / 8 + 9;
+            if (f.src_rows > h) f.src_rows = h;
+        }
+    }
     const int nbands = (H + f.BH - 1) / f.BH;
-    const size_t lds = sizeof(float) * ((size_t)f.src_rows * w + (size_t)(f.BH + 2) * (w + 8));
-    if (lds > 60000) return PD_E_STATE;
+    if (nbands > KF_MAX_BANDS) return PD_E_STATE;
+    for (int band = 0; band < nbands; ++band) {
+        const int Yb = band * f.BH;
+        const int Ylo = Yb - 1 < 0 ? 0 : Yb - 1;
+        const int Yhi = Yb + f.BH > H - 1 ? H - 1 : Yb + f.BH;
+        const int sb0 = ctx->kf_ystart_host[Ylo];
+        int sb1 = ctx->kf_ystart_host[Yhi] + 7;
+        if (sb1 > h - 1) sb1 = h - 1;
+        int ns = sb1 - sb0 + 1;
+        if (ns > f.src_rows) return PD_E_STATE;
+        f.band_sb0[band] = sb0;
+        f.band_ns[band] = ns;
+    }
+    // LDS: coefficients + starts (9 per row), source rows (+8 zero rows), T rows
+    const size_t lds = sizeof(float) * ((size_t)(f.BH + 2) * 9 + (size_t)(f.src_rows + 8) * w + (size_t)(f.BH + 2) * (w + 8));
+    if (lds > 64000) return PD_E_STATE;
+    PD_HIP(ctx, hipMemsetAsync(ctx->cand_count, 0, sizeof(int32_t) * B * PD_N_PARTS, ctx->stream));
+    PD_HIP(ctx, hipMemsetAsync(ctx->absmax, 0, sizeof(float) * B, ctx->stream));
     pd_prof_begin(ctx, PD_STAGE_FILTER);
+    hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
+                       h * w, ctx->heat_planar, (unsigned int*)ctx->absmax);
     hipLaunchKernelGGL(k_prefilter, dim3(nbands, PD_N_PARTS, B), dim3(KF_NT), lds, ctx->stream, f);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());

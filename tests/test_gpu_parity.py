@@ -81,6 +81,29 @@ def test_multi_person_parse_cases(pp):
         gio.assert_persons_equal(persons, g[pre + 'persons'], RTOL)
 
 
+def test_parse_more_than_64_open_persons(pp):
+    """More live person rows than one wavefront has lanes: the register-resident
+    parser hands the image to the LDS-table kernel."""
+    rng = np.random.RandomState(8)
+    n = 90
+    peaks, pid = [], 0
+    for part in range(18):
+        peaks.append([(np.int64(rng.randint(0, 300)), np.int64(rng.randint(0, 300)), np.float64(0.5 + rng.rand()), pid + i)
+                      for i in range(n)])
+        pid += n
+    conns, special = [], []
+    for k in range(19):
+        a, b = ref.LIMB_FROM[k], ref.LIMB_TO[k]
+        perm = rng.permutation(n) if k in (3, 7, 12) else np.arange(n)
+        rows = [[peaks[a][i][3], peaks[b][perm[i]][3], 0.6 + 0.3 * rng.rand(), peaks[a][i][2], peaks[b][perm[i]][2]]
+                for i in range(n)]
+        conns.append(np.array(rows))
+    want = ref.multi_person_parse(peaks, conns, special, 'P')
+    got = pp.multi_person_parse(peaks, conns, special)
+    assert len(want) > 64
+    gio.assert_persons_equal(got, want, RTOL)
+
+
 @pytest.mark.parametrize('impl', [0, 1])
 @pytest.mark.parametrize('shape,dtype', [((40, 50), np.float64), ((40, 50), np.float32),
                                          ((5, 7), np.float64), ((368, 368), np.float64),
@@ -178,6 +201,34 @@ def test_candidate_filter_equals_exact_kernel(pdec, kind, thr, pk, h, w, H, W):
     assert np.array_equal(out[0]['peaks'], out[1]['peaks'])
     if kind in ('noise', 'plateau', 'ridge'):
         assert out[0]['peaks'].size > 0
+
+
+@pytest.mark.parametrize('profile', [False, True])
+def test_device_resident_replay_follows_the_data(pdec, profile):
+    """Device-resident inputs go through the captured launch graph from the third call
+    on; the graph must read the buffers' current contents and report per-stage times."""
+    import torch
+    from poseestimation_amd import synth
+    H = W = 184
+    batches = [synth.batch(3, H, W, (1, 3), seed0=s, paf_order='xy') for s in (50, 60)]
+    d_heat = torch.empty((3, 23, 23, 19), dtype=torch.float32, device='cuda')
+    d_paf = torch.empty((3, 23, 23, 38), dtype=torch.float32, device='cuda')
+    eng = pdec.DecodeEngine(max_batch=3, max_h=H, max_w=W, mode='D')
+    eng.ctx.profile(profile)
+    want = [pdec.DecodeEngine(3, H, W, mode='D').decode_batch(h, p).packed for h, p in batches]
+    for it in range(6):
+        heat, paf = batches[it % 2]
+        d_heat.copy_(torch.from_numpy(heat))
+        d_paf.copy_(torch.from_numpy(paf))
+        torch.cuda.synchronize()
+        eng.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), 3, 23, 23, (H, W))
+        got = eng.fetch().packed
+        for key in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
+            assert np.array_equal(got[key], want[it % 2][key]), (it, key)
+    if profile:
+        prof = eng.ctx.profile_read()
+        assert prof['filter'][1] == 6 and prof['filter'][0] > 0 and prof['pack'][1] == 6
+    eng.close()
 
 
 @pytest.mark.parametrize('seed,P,H,W', [(21, 4, 368, 368), (22, 6, 200, 312), (23, 1, 96, 96)])
