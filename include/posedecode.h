@@ -187,7 +187,8 @@ enum {
     PD_STAGE_PACK = 6,       /* result packing */
     PD_STAGE_FILTER = 7,     /* float32 composite-kernel candidate filter */
     PD_STAGE_VERIFY = 8,     /* exact float64 verification of the candidates */
-    PD_N_STAGES = 9
+    PD_STAGE_PLANAR = 9,     /* (h, w, 19) -> planar copy of the heatmaps + max |v| */
+    PD_N_STAGES = 10
 };
 int pd_profile(pd_ctx* ctx, int enable);
 int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);

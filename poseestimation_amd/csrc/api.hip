@@ -172,6 +172,7 @@ MapSource pd_heat_source(const pd_ctx* ctx) {
     s.Cfull = PD_CH_HEAT;
     s.ty = ctx->tabs[0].ty;
     s.tx = ctx->tabs[0].tx;
+    pd_up8_fill(&s.up8);
     return s;
 }
 
@@ -219,6 +220,9 @@ extern "C" int pd_set_lowres(pd_ctx* ctx, const float* heat, const float* paf, i
             ctx->lo_paf = ctx->stage_paf;
         }
     } else {
+        // the kernels read the maps with 8- and 16-byte loads
+        if (((uintptr_t)heat | (uintptr_t)paf) & 15)
+            PD_FAIL(ctx, PD_E_INVALID, "pd_set_lowres: device arrays must be 16-byte aligned");
         if (heat) ctx->lo_heat = heat;
         if (paf) ctx->lo_paf = paf;
     }

@@ -39,6 +39,17 @@ struct CubicTable {
     const float* coef;   // [n][4]
 };
 
+// Closed form of the x8 tap table (cv2.resize(.., fx=8, fy=8)): the source coordinate
+// of destination index d is (d - 3.5) / 8, so the first tap is ((d - 4) >> 3) - 1 and
+// the fractional part -- hence the four weights -- depends only on (d - 4) & 7.  The
+// weights are the table's own entries (computed once on the host), so values are
+// bit-identical to the table path.
+struct Up8 {
+    float c[8][4];
+};
+__host__ __device__ inline int pd_up8_ofs(int d) { return ((d - 4) >> 3) - 1; }
+__host__ __device__ inline int pd_up8_phase(int d) { return (d - 4) & 7; }
+
 // Where the full-resolution heat / PAF values come from.
 struct MapSource {
     int kind;             // PD_SRC_LOWRES or PD_SRC_FULLRES
@@ -49,6 +60,7 @@ struct MapSource {
     const double* full;   // (B, Cfull, H, W) float64 planes
     int Cfull;
     CubicTable ty, tx;    // x8 tables of length H and W
+    Up8 up8;              // the same weights by phase
 };
 
 // Byte layout of the packed result buffer of a batch of B images:
@@ -248,5 +260,6 @@ int pd_launch_hwc_to_planar(pd_ctx* ctx, const void* src, int dtype, int Csrc, i
 int pd_launch_planar_to_hwc(pd_ctx* ctx, const double* src, int C, int B, int H, int W, double* dst);
 int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W);
 void pd_host_cubic_table(int src_len, int dst_len, double scale, int32_t* ofs, float* coef);
+void pd_up8_fill(Up8* u);
 MapSource pd_heat_source(const pd_ctx* ctx);
 MapSource pd_paf_source(const pd_ctx* ctx);

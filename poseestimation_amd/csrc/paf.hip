@@ -31,26 +31,33 @@ struct PairArgs {
 
 // Two adjacent channels (ch, ch+1) of a (h, w, C) float32 map, bicubic at (Y, X);
 // same arithmetic as pd_bicubic_at.
+// Taps and weights come from the closed form of the x8 table (weights by phase in LDS),
+// the two channels of one pixel from one 8-byte load (ch even, C even).
 __device__ __forceinline__ void bicubic2_at(const float* __restrict__ img, int h, int w, int C, int ch, int Y,
-                                            int X, const CubicTable& ty, const CubicTable& tx, float* o0,
-                                            float* o1) {
-    const int x0 = tx.ofs[X];
-    const int y0 = ty.ofs[Y];
-    const float a0 = tx.coef[4 * X + 0], a1 = tx.coef[4 * X + 1], a2 = tx.coef[4 * X + 2],
-                a3 = tx.coef[4 * X + 3];
-    const size_t xi0 = (size_t)pd_clampi(x0, 0, w - 1) * C, xi1 = (size_t)pd_clampi(x0 + 1, 0, w - 1) * C,
-                 xi2 = (size_t)pd_clampi(x0 + 2, 0, w - 1) * C, xi3 = (size_t)pd_clampi(x0 + 3, 0, w - 1) * C;
-    float h0[4], h1[4];
+                                            int X, const float4* __restrict__ up, float* o0, float* o1) {
+    const int x0 = pd_up8_ofs(X);
+    const int y0 = pd_up8_ofs(Y);
+    const float4 ac = up[pd_up8_phase(X)];
+    const float4 bc = up[pd_up8_phase(Y)];
+    const int xi0 = pd_clampi(x0, 0, w - 1) * C, xi1 = pd_clampi(x0 + 1, 0, w - 1) * C,
+              xi2 = pd_clampi(x0 + 2, 0, w - 1) * C, xi3 = pd_clampi(x0 + 3, 0, w - 1) * C;
+    float2 v[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float* row = img + ((size_t)pd_clampi(y0 + k, 0, h - 1) * w) * C + ch;
-        h0[k] = ((row[xi0] * a0 + row[xi1] * a1) + row[xi2] * a2) + row[xi3] * a3;
-        h1[k] = ((row[xi0 + 1] * a0 + row[xi1 + 1] * a1) + row[xi2 + 1] * a2) + row[xi3 + 1] * a3;
+        v[k][0] = *(const float2*)(row + xi0);
+        v[k][1] = *(const float2*)(row + xi1);
+        v[k][2] = *(const float2*)(row + xi2);
+        v[k][3] = *(const float2*)(row + xi3);
     }
-    const float b0 = ty.coef[4 * Y + 0], b1 = ty.coef[4 * Y + 1], b2 = ty.coef[4 * Y + 2],
-                b3 = ty.coef[4 * Y + 3];
-    *o0 = ((h0[0] * b0 + h0[1] * b1) + h0[2] * b2) + h0[3] * b3;
-    *o1 = ((h1[0] * b0 + h1[1] * b1) + h1[2] * b2) + h1[3] * b3;
+    float h0[4], h1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h0[k] = ((v[k][0].x * ac.x + v[k][1].x * ac.y) + v[k][2].x * ac.z) + v[k][3].x * ac.w;
+        h1[k] = ((v[k][0].y * ac.x + v[k][1].y * ac.y) + v[k][2].y * ac.z) + v[k][3].y * ac.w;
+    }
+    *o0 = ((h0[0] * bc.x + h0[1] * bc.y) + h0[2] * bc.z) + h0[3] * bc.w;
+    *o1 = ((h1[0] * bc.x + h1[1] * bc.y) + h1[2] * bc.z) + h1[3] * bc.w;
 }
 
 // 16 lanes per candidate pair: lanes 0..9 take one sample point each, then the ten
@@ -59,8 +66,13 @@ __global__ void __launch_bounds__(256)
 k_pair_scores(PairArgs a) {
     __shared__ int32_t s_off[PD_N_LIMBS + 1];
     __shared__ int32_t s_cnt[PD_N_PARTS];
+    __shared__ float4 s_up[8];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
+    if (tid >= 64 && tid < 72) {
+        const float* c = a.src.up8.c[tid - 64];
+        s_up[tid - 64] = make_float4(c[0], c[1], c[2], c[3]);
+    }
     if (tid <= PD_N_LIMBS) s_off[tid] = a.pair_off[b * (PD_N_LIMBS + 1) + tid];
     if (tid < PD_N_PARTS) s_cnt[tid] = a.part_count[b * PD_N_PARTS + tid];
     __syncthreads();
@@ -127,7 +139,7 @@ k_pair_scores(PairArgs a) {
                 if (a.src.kind == PD_SRC_LOWRES) {
                     float f0, f1;
                     bicubic2_at(a.src.lo + (size_t)b * a.src.h * a.src.w * a.src.C, a.src.h, a.src.w, a.src.C,
-                                2 * k, iy, ix, a.src.ty, a.src.tx, &f0, &f1);
+                                2 * k, iy, ix, s_up, &f0, &f1);
                     v0 = (double)f0;
                     v1 = (double)f1;
                 } else {

@@ -174,10 +174,10 @@ struct FilterArgs {
     const float* xcoef;
     const float* absmax;  // [B]
     double thr;
-    int32_t* cand;
-    int32_t* cand_count;
+    int2* cand;            // (plane, y << 16 | x), all planes in one list
+    int32_t* cand_count;   // [B][18] candidates seen per plane (may exceed CK)
+    int32_t* cand_total;   // entries in cand
     int CK;
-    int dbg;  // timing experiments only (PD_KF_DEBUG): 1 = stop before the column pass
     int band_sb0[KF_MAX_BANDS];  // first source row staged for each band
     int band_ns[KF_MAX_BANDS];   // number of source rows staged
 };
@@ -213,7 +213,6 @@ k_prefilter(FilterArgs a) {
         ysL[i] = (Y >= 0 && Y < H) ? a.ystart[Y] - sb0 : 0;
     }
     __syncthreads();
-    if (a.dbg == 2) return;
 
     // rows: T[Yr][t], Yr = Y - (Yb - 1).  A thread owns one source column t and a run
     // of consecutive rows: the eight source values of its window stay in registers and
@@ -261,7 +260,7 @@ k_prefilter(FilterArgs a) {
 
     // columns + tolerant NMS: thread = (column group g, row lane rl)
     const int g = tid % a.wg, rl = tid / a.wg;
-    if (rl >= a.RL || a.dbg == 1) return;
+    if (rl >= a.RL) return;
     // coefficients: the eight real columns as four pairs for packed FMAs (all use
     // window positions 1..7), the two halo columns (positions 0..6 and 2..8) scalar
     float2v kp[4][7];
@@ -286,7 +285,6 @@ k_prefilter(FilterArgs a) {
     for (int j = 0; j < 8; ++j) prev2[j] = 0.f;
     const int Y0 = Yb + rl * a.RB;  // first row this thread decides
     int32_t* plane_count = a.cand_count + b * PD_N_PARTS + part;
-    int32_t* plane_list = a.cand + ((size_t)b * PD_N_PARTS + part) * a.CK;
     for (int it = 0; it < a.RB + 2; ++it) {
         const int Y = Y0 - 1 + it;  // row being evaluated; row Y - 1 is decided
         const float* tp = T + (size_t)(Y - (Yb - 1)) * tw + g;
@@ -354,8 +352,13 @@ k_prefilter(FilterArgs a) {
                         const bool ok = X < W && c > thr_lo && ce >= prev2[j] && ce >= cur[j + 1] &&
                                         ce >= prev1[j] && ce >= prev1[j + 2];
                         if (ok) {
+                            // the per-plane count decides overflow, the list itself is one
+                            // global array so the verification is balanced over the chip
                             const int pos = atomicAdd(plane_count, 1);
-                            if (pos < a.CK) plane_list[pos] = (Yc << 16) | X;
+                            if (pos < a.CK) {
+                                const int gi = atomicAdd(a.cand_total, 1);
+                                a.cand[gi] = make_int2(b * PD_N_PARTS + part, (Yc << 16) | X);
+                            }
                         }
                     }
                 }
@@ -369,69 +372,73 @@ k_prefilter(FilterArgs a) {
 }
 
 struct VerifyArgs {
-    MapSource src;
+    const float* lo;  // planar copy (B, 19, h, w)
+    int h, w, H, W;
+    Up8 up8;
     double thr;
-    const int32_t* cand;
+    const int2* cand;
     const int32_t* cand_count;
+    const int32_t* cand_total;
     int CK;
     RawPeak* raw;
     int32_t* raw_count;
     int PK;
 };
 
-// One workgroup per (part, image); 32 lanes per candidate, 8 candidates per pass.
-// Lane l < 27 owns column X + l - 13: it loads the (at most 8) source rows the 27
-// bicubic rows Y-13 .. Y+13 draw on, forms their horizontal 4-tap sums once, then the
-// 27 vertical sums and the three y-pass sums; five lanes finish the x pass.
+// Exact float64 decision for every candidate.  32 lanes per candidate, 8 candidates per
+// workgroup pass, workgroups stride over the global list.  Lane l < 27 owns column
+// X + l - 13: it forms the horizontal 4-tap sums of the (at most 8) source rows that the
+// 27 bicubic rows Y-13 .. Y+13 draw on, then the 27 vertical sums and the three y-pass
+// sums (rows Y-1, Y, Y+1); five lanes finish the x pass (centre and four neighbours).
 __global__ void __launch_bounds__(256, 2)
 k_verify(VerifyArgs a) {
     __shared__ double ypL[8][3][28];
     __shared__ float hvL[8][256];
-    const int part = blockIdx.x, b = blockIdx.y;
-    const int plane = b * PD_N_PARTS + part;
-    const int n = a.cand_count[plane];
-    if (n <= 0 || n > a.CK) return;  // overflowing planes are redone by the exact kernel
+    __shared__ float4 s_up[8];
     const int tid = threadIdx.x;
     const int half = tid >> 5, l = tid & 31;
-    const int H = a.src.H, W = a.src.W, h = a.src.h, w = a.src.w, C = a.src.C;
-    const int32_t* list = a.cand + (size_t)plane * a.CK;
-    const float* img = a.src.lo + (size_t)b * h * w * C + part;
-    for (int base = 0; base < n; base += 8) {
+    if (tid < 8) s_up[tid] = make_float4(a.up8.c[tid][0], a.up8.c[tid][1], a.up8.c[tid][2], a.up8.c[tid][3]);
+    const int total = *a.cand_total;
+    const int H = a.H, W = a.W, h = a.h, w = a.w;
+    __syncthreads();
+    for (int base = blockIdx.x * 8; base < total; base += gridDim.x * 8) {
         const int ci = base + half;
-        const bool active = ci < n;
-        int Y = 0, X = 0;
+        bool active = ci < total;
+        int Y = 0, X = 0, plane = 0;
         double u13 = 0.0;
         if (active) {
-            const int packed = list[ci];
-            Y = packed >> 16;
-            X = packed & 0xffff;
+            const int2 e = a.cand[ci];
+            plane = e.x;
+            Y = e.y >> 16;
+            X = e.y & 0xffff;
+            active = a.cand_count[plane] <= a.CK;  // overflowing planes are redone by the exact kernel
         }
         if (active && l < 27) {
-            // source-row range of the 27 (reflected) rows
-            int rmin = H, rmax = 0;
-#pragma unroll
-            for (int i = 0; i < 27; ++i) {
-                const int r = pd_reflect(Y - 13 + i, H);
-                rmin = min(rmin, r);
-                rmax = max(rmax, r);
-            }
-            const int ymin = a.src.ty.ofs[rmin];
+            const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
+            const float* img = a.lo + ((size_t)b * PD_CH_HEAT + part) * h * w;
+            // the reflected rows Y-13 .. Y+13 all lie in [max(Y-13, 0), min(Y+13, H-1)]
+            const int rmin = max(Y - 13, 0);
+            const int ymin = pd_up8_ofs(rmin);
             const int col = pd_reflect(X + l - 13, W);
-            const int x0 = a.src.tx.ofs[col];
-            const float4 ac = *(const float4*)(a.src.tx.coef + 4 * (size_t)col);
-            const size_t xi0 = (size_t)pd_clampi(x0, 0, w - 1) * C, xi1 = (size_t)pd_clampi(x0 + 1, 0, w - 1) * C,
-                         xi2 = (size_t)pd_clampi(x0 + 2, 0, w - 1) * C, xi3 = (size_t)pd_clampi(x0 + 3, 0, w - 1) * C;
+            const int x0 = pd_up8_ofs(col);
+            const float4 ac = s_up[pd_up8_phase(col)];
+            const int xi0 = pd_clampi(x0, 0, w - 1), xi1 = pd_clampi(x0 + 1, 0, w - 1),
+                      xi2 = pd_clampi(x0 + 2, 0, w - 1), xi3 = pd_clampi(x0 + 3, 0, w - 1);
+            float4 sv[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float* row = img + ((size_t)pd_clampi(ymin + q, 0, h - 1) * w) * C;
-                hvL[q][tid] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
+                const float* row = img + (size_t)pd_clampi(ymin + q, 0, h - 1) * w;
+                sv[q] = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                hvL[q][tid] = ((sv[q].x * ac.x + sv[q].y * ac.y) + sv[q].z * ac.z) + sv[q].w * ac.w;
             double u[27];
 #pragma unroll
             for (int i = 0; i < 27; ++i) {
                 const int r = pd_reflect(Y - 13 + i, H);
-                const int d = min(a.src.ty.ofs[r] - ymin, 4);
-                const float4 bc = *(const float4*)(a.src.ty.coef + 4 * (size_t)r);
+                const int d = min(pd_up8_ofs(r) - ymin, 4);
+                const float4 bc = s_up[pd_up8_phase(r)];
                 const float v = ((hvL[d][tid] * bc.x + hvL[d + 1][tid] * bc.y) + hvL[d + 2][tid] * bc.z) +
                                 hvL[d + 3][tid] * bc.w;
                 u[i] = (double)v;
@@ -494,8 +501,8 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         ctx->cand = nullptr;
         ctx->cand_count = nullptr;
         ctx->absmax = nullptr;
-        PD_HIP(ctx, hipMalloc(&ctx->cand, sizeof(int32_t) * (size_t)ctx->cfg.max_batch * PD_N_PARTS * CK));
-        PD_HIP(ctx, hipMalloc(&ctx->cand_count, sizeof(int32_t) * (size_t)ctx->cfg.max_batch * PD_N_PARTS));
+        PD_HIP(ctx, hipMalloc(&ctx->cand, sizeof(int2) * (size_t)ctx->cfg.max_batch * PD_N_PARTS * CK));
+        PD_HIP(ctx, hipMalloc(&ctx->cand_count, sizeof(int32_t) * ((size_t)ctx->cfg.max_batch * PD_N_PARTS + 1)));
         PD_HIP(ctx, hipMalloc(&ctx->absmax, sizeof(float) * (size_t)ctx->cfg.max_batch));
         ctx->cand_cap = CK;
     }
@@ -542,20 +549,10 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     f.xcoef = ctx->kf_xcoef;
     f.absmax = ctx->absmax;
     f.thr = thr;
-    f.cand = ctx->cand;
+    f.cand = (int2*)ctx->cand;
     f.cand_count = ctx->cand_count;
+    f.cand_total = ctx->cand_count + (size_t)B * PD_N_PARTS;  // one more counter behind the planes'
     f.CK = CK;
-    {
-        const char* e = getenv("PD_KF_DEBUG");
-        f.dbg = e ? atoi(e) : 0;
-        const char* r = getenv("PD_KF_RB");
-        if (r && atoi(r) >= 8) {
-            f.RB = atoi(r);
-            f.BH = f.RL * f.RB;
-            f.src_rows = (f.BH + 26) / 8 + 9;
-            if (f.src_rows > h) f.src_rows = h;
-        }
-    }
     const int nbands = (H + f.BH - 1) / f.BH;
     if (nbands > KF_MAX_BANDS) return PD_E_STATE;
     for (int band = 0; band < nbands; ++band) {
@@ -573,25 +570,36 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     // LDS: coefficients + starts (9 per row), source rows (+8 zero rows), T rows
     const size_t lds = sizeof(float) * ((size_t)(f.BH + 2) * 9 + (size_t)(f.src_rows + 8) * w + (size_t)(f.BH + 2) * (w + 8));
     if (lds > 64000) return PD_E_STATE;
-    PD_HIP(ctx, hipMemsetAsync(ctx->cand_count, 0, sizeof(int32_t) * B * PD_N_PARTS, ctx->stream));
+    PD_HIP(ctx, hipMemsetAsync(ctx->cand_count, 0, sizeof(int32_t) * ((size_t)B * PD_N_PARTS + 1), ctx->stream));
     PD_HIP(ctx, hipMemsetAsync(ctx->absmax, 0, sizeof(float) * B, ctx->stream));
-    pd_prof_begin(ctx, PD_STAGE_FILTER);
+    pd_prof_begin(ctx, PD_STAGE_PLANAR);
     hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
                        h * w, ctx->heat_planar, (unsigned int*)ctx->absmax);
+    pd_prof_end(ctx);
+    pd_prof_begin(ctx, PD_STAGE_FILTER);
     hipLaunchKernelGGL(k_prefilter, dim3(nbands, PD_N_PARTS, B), dim3(KF_NT), lds, ctx->stream, f);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     VerifyArgs v;
-    v.src = pd_heat_source(ctx);
+    v.lo = ctx->heat_planar;
+    v.h = h;
+    v.w = w;
+    v.H = H;
+    v.W = W;
+    pd_up8_fill(&v.up8);
     v.thr = thr;
-    v.cand = ctx->cand;
+    v.cand = (const int2*)ctx->cand;
     v.cand_count = ctx->cand_count;
+    v.cand_total = f.cand_total;
     v.CK = CK;
     v.raw = ctx->raw;
     v.raw_count = ctx->raw_count;
     v.PK = ctx->cfg.max_peaks_per_part;
+    // the list length is only known on the device: a fixed grid strides over it
+    int vblocks = B * 12;
+    if (vblocks > 1024) vblocks = 1024;
     pd_prof_begin(ctx, PD_STAGE_VERIFY);
-    hipLaunchKernelGGL(k_verify, dim3(PD_N_PARTS, B), dim3(256), 0, ctx->stream, v);
+    hipLaunchKernelGGL(k_verify, dim3(vblocks), dim3(256), 0, ctx->stream, v);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     // planes whose candidates did not fit

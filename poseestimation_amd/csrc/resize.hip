@@ -37,6 +37,15 @@ void pd_host_cubic_table(int src_len, int dst_len, double scale, int32_t* ofs, f
     }
 }
 
+// Weights of the x8 table by phase: destination indices 4..11 have phases 0..7.
+void pd_up8_fill(Up8* u) {
+    int32_t ofs[16];
+    float coef[64];
+    pd_host_cubic_table(2, 16, 0.125, ofs, coef);
+    for (int p = 0; p < 8; ++p)
+        for (int k = 0; k < 4; ++k) u->c[p][k] = coef[4 * (4 + p) + k];
+}
+
 // Device tables: ints [y ofs | x ofs], floats [y coef | x coef].
 static int upload_tables(pd_ctx* ctx, int hs, int ws, int Hd, int Wd, double sy, double sx,
                          TableSlot* slot) {
