@@ -163,6 +163,7 @@ def main():
         }
         res0 = last
         out['persons_last_step'] = int(res0['person_count'].sum())
+        out['filter_stats_last_step'] = eng.ctx.filter_stats()
 
         if world == 1 and not args.no_cpu:
             from oracle import decode_ref as ref

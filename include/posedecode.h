@@ -188,7 +188,8 @@ enum {
     PD_STAGE_FILTER = 7,     /* float32 composite-kernel candidate filter */
     PD_STAGE_VERIFY = 8,     /* exact float64 verification of the candidates */
     PD_STAGE_PLANAR = 9,     /* (h, w, 19) -> planar copy of the heatmaps + max |v| */
-    PD_N_STAGES = 10
+    PD_STAGE_CELLS = 10,     /* active-cell scan at network resolution */
+    PD_N_STAGES = 11
 };
 int pd_profile(pd_ctx* ctx, int enable);
 int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);
@@ -196,6 +197,13 @@ int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);
 /* The smoothed heatmap the peak stage compares (scipy.ndimage.gaussian_filter,
  * sigma = 3), (B, 18, H, W) float64; test hook for the filter alone. */
 int pd_debug_smoothed(pd_ctx* ctx, double* out);
+
+/* Counters of the last peak stage that went through the candidate filter
+ * (PD_IMPL_FAST on network-resolution sources): out[0] candidates handed to the exact
+ * verification, out[1] / out[2] active 8 x 8 pixel cells with interior / border
+ * weights, out[3] planes redone by the exact kernel because their candidate list
+ * overflowed.  Waits for the stream.  No counterpart in the reference; diagnostics. */
+int pd_filter_stats(pd_ctx* ctx, int64_t* out);
 
 #ifdef __cplusplus
 }

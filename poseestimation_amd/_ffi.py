@@ -21,9 +21,9 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats']
 
-STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar']
+STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells']
 
 
 class Config(C.Structure):
@@ -121,6 +121,7 @@ def lib():
     L.pd_packed_device.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.pd_results_host.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.pd_profile.argtypes = [vp, i32]
+    L.pd_filter_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -301,6 +302,13 @@ class Context:
         ptrs = [C.c_void_p() for _ in range(6)]
         self.check(self.L.pd_packed_device(self._h, *[C.byref(p) for p in ptrs]))
         return [p.value for p in ptrs]
+
+    def filter_stats(self):
+        """Counters of the last filtered peak stage: candidates, interior cells, border
+        cells, planes redone by the exact kernel."""
+        out = (C.c_int64 * 4)()
+        self.check(self.L.pd_filter_stats(self._h, out))
+        return dict(candidates=out[0], cells_interior=out[1], cells_border=out[2], planes_exact=out[3])
 
     def debug_smoothed(self, B, H, W):
         out = np.empty((B, 18, H, W), np.float64)

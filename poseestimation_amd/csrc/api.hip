@@ -3,6 +3,8 @@
 
 #include <new>
 
+#include <vector>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -127,14 +129,13 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->tabs[1].f, ctx->tabs[2].i, ctx->tabs[2].f, ctx->raw, ctx->raw_count, ctx->pk_y,
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
-                    ctx->person_count, ctx->status, ctx->pack_off, ctx->res_dev, ctx->kf_ystart, ctx->kf_ycoef, ctx->kf_xcoef, ctx->cand,
+                    ctx->person_count, ctx->status, ctx->pack_off, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
                     ctx->cand_count, ctx->absmax, ctx->heat_planar};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->res_host) (void)hipHostFree(ctx->res_host);
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
-    free(ctx->kf_ystart_host);
     free(ctx->prof_ev);
     free(ctx->prof_stage);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -403,6 +404,26 @@ extern "C" int pd_debug_smoothed(pd_ctx* ctx, double* out) {
     }
     (void)hipFree(dev);
     return rc;
+}
+
+extern "C" int pd_filter_stats(pd_ctx* ctx, int64_t* out) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!out) PD_FAIL(ctx, PD_E_INVALID, "pd_filter_stats: out is NULL");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!ctx->cand_count || ctx->B < 1) return PD_OK;
+    const size_t planes = (size_t)ctx->B * PD_N_PARTS;
+    const int nseg = 32;  // segments per list (KF_NSEG of the filter)
+    std::vector<int32_t> host(planes + 3 * nseg);
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PD_HIP(ctx, hipMemcpy(host.data(), ctx->cand_count, sizeof(int32_t) * host.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nseg; ++i) {
+        out[0] += host[planes + i];
+        out[1] += host[planes + nseg + i];
+        out[2] += host[planes + 2 * nseg + i];
+    }
+    for (size_t i = 0; i < planes; ++i) out[3] += host[i] > ctx->cand_cap;
+    return PD_OK;
 }
 
 extern "C" int pd_set_peaks(pd_ctx* ctx, const int32_t* counts, const int32_t* y, const int32_t* x,

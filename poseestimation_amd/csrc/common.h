@@ -132,13 +132,13 @@ struct pd_ctx {
     // ---- candidate filter (float32 composite of bicubic x8 and Gaussian) ----
     int kf_ok;                       // tables valid for (kf_h, kf_w, kf_H, kf_W)
     int kf_h, kf_w, kf_H, kf_W;
-    int32_t* kf_ystart;              // [H] first source row of the 8-tap window
-    int32_t* kf_ystart_host;         // host copy (band geometry is derived from it)
-    float* kf_ycoef;                 // [H][8]
-    float* kf_xcoef;                 // [ceil(W/8)][10][7]
-    size_t kf_ycap, kf_xcap;
-    int32_t* cand;                   // [B][18][CK] packed (y << 16 | x)
-    int32_t* cand_count;             // [B][18]
+    float* kf_tab;                   // per 8-pixel cell row / column: 10 x 7 composite weights and bound weights
+    int32_t* kf_reg;                 // [hc] | [wc]: 1 = the cell row / column has the interior weights
+    size_t kf_tab_cap, kf_reg_cap;   // in elements
+    int32_t* cells;                  // active cells: regular ones from the front, border ones from the back
+    size_t cells_cap;
+    int32_t* cand;                   // candidate list, int2 (plane, y << 16 | x)
+    int32_t* cand_count;             // [B][18] candidates per plane | list length | cell counts
     float* absmax;                   // [B] max |heat| per image
     float* heat_planar;              // (B, 19, h, w) copy of the network heatmaps
     size_t heat_planar_cap;

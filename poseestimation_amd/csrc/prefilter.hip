@@ -1,20 +1,32 @@
-// Fast peak stage for network-resolution sources: a float32 candidate filter followed
-// by exact float64 verification of the few candidates.  Results are identical to the
-// exact kernel over every pixel (get_peaks, utils/postprocess.py:26-75).
+// Fast peak stage for network-resolution sources: a float32 candidate filter over the
+// active part of the map followed by exact float64 verification of the few candidates.
+// Results are identical to the exact kernel over every pixel (get_peaks,
+// utils/postprocess.py:26-75).
 //
 // Filter.  The smoothed map is a linear function of the (h, w) network output:
 // Gaussian (25 taps, reflect) after bicubic x8 (4 taps, clamped) composes, per axis,
-// into a banded operator with 7 taps per output.  The filter evaluates
-//     T[Y][t]  = sum_k Ky[Y][k] * src[s0(Y)+k][t]          (rows)
-//     S~[Y][X] = sum_p Kx[X][p] * T[Y][t0(X)+p]            (columns)
-// in float32 with fused multiply-adds.  Against the exact float64 value S of the
-// reference (which is computed from the float32-rounded bicubic map),
+// into a banded operator with 7 taps per output,
+//     S~[Y][X] = sum_s sum_t Ky[Y][s] * Kx[X][t] * src[s][t].
+// In units of 8 x 8 pixel cells (cell c of an axis = outputs 8c .. 8c+7, plus one halo
+// output either side) output 8c-1+j draws on sources c-4+p0(j) .. c+2+p0(j), with
+// p0 = 0 for j = 0, 1 for j = 1..8, 2 for j = 9; border effects (clamped taps,
+// reflected rows) only change the weights, not the windows, and all cells away from
+// the border share one set of weights.  The filter evaluates S~ in float32 with fused
+// multiply-adds.  Against the exact float64 value S of the reference (which is computed
+// from the float32-rounded bicubic map),
 //     |S~ - S| <= 53 * 2^-24 * 1.89 * M  <  eps := 2^-17 * M,   M >= max |src| of the plane
-// (coefficient rounding, 8-term chains on both axes, and the rounding inside the
-// reference's own float32 bicubic; sum_k |K| <= 1.375 per axis).  A pixel can only be
+// (coefficient rounding, 7-term chains on both axes, and the rounding inside the
+// reference's own float32 bicubic; sum |K| <= 1.375 per axis).  A pixel can only be
 // a peak (S > thr, S >= each in-image neighbour, S >= 0 for out-of-image ones) if
 //     S~ > thr - eps  and  S~ >= S~(neighbour) - 2 eps,
 // so every true peak is among the candidates.
+//
+// Active cells.  |S~| over a cell is at most
+//     U = sum_s sum_t By[s] * Bx[t] * |src[s][t]|,   B = the largest |weight| any of the
+// cell's eight own outputs puts on that source,
+// a 7 x 7 separable sum on the network-resolution map.  Cells with U below the threshold
+// cannot hold a candidate and are never touched at full resolution; typical maps leave a
+// few percent of the cells.
 //
 // Verification.  Per candidate the exact S at the pixel and its four neighbours is
 // recomputed with the reference's arithmetic (27 x 27 bicubic values, 77 y-pass sums,
@@ -23,17 +35,36 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "colloader.h"
 
 #pragma clang fp contract(off)
 
-#define KF_NT 256
-#define KF_MAX_BANDS 32
-typedef float float2v __attribute__((ext_vector_type(2)));
+#define KF_CELLS_PER_WAVE 6   // ten lanes per cell
+#define KF_CELLS_PER_BLOCK 24
+#define KF_LCAND 512          // candidates staged in LDS per workgroup between flushes
+#define KF_OVERFLOW (1 << 30)  // or-ed into a plane's candidate count: more than any list length
+// The cell list and the candidate list are filled by thousands of workgroups.  Atomics
+// on one address serialise chip-wide (tens of nanoseconds each), so each list is split
+// into KF_NSEG segments with a counter of their own; readers rebuild the global order
+// from the 32 counts.
+#define KF_NSEG 32
 
 static const double h_gw[PD_GTAPS] = PD_GAUSS_WEIGHTS;
+
+// The weights of a cell away from the border are the same on both axes and for every map
+// size.  They live in constant memory so that they reach the multiply-adds as scalar
+// operands; the kernels re-derive the pointer inside the cell loop (fresh_pointer) so that
+// the 70 scalar loads stay next to their uses instead of being hoisted and spilled.
+__constant__ float c_kf_interior[72];
+typedef __attribute__((address_space(4))) float ConstF;
+__device__ __forceinline__ const ConstF* fresh_pointer(const float* p) {
+    const ConstF* q = (const ConstF*)p;
+    asm volatile("" : "+s"(q));
+    return q;
+}
 
 static int host_reflect(int i, int n) {
     const int p = 2 * n;
@@ -57,6 +88,69 @@ static void composite(int L, int l, const int32_t* ofs, const float* coef, std::
         }
 }
 
+// One axis in cell form: cw[c][j * 7 + p] = weight of source c-4+p0(j)+p in output
+// 8c-1+j (zero for outputs outside the map), bw[c][p] = max over j = 1..8 of
+// |cw[c][j * 7 + p]| (sources c-3 .. c+3).  False if some weight falls outside its window.
+static bool cell_weights(int L, int l, const std::vector<double>& K, std::vector<float>& cw, std::vector<float>& bw,
+                         std::vector<int32_t>& reg, const float* interior) {
+    const int nc = (L + 7) / 8;
+    cw.assign((size_t)nc * 72, 0.f);
+    bw.assign((size_t)nc * 8, 0.f);
+    for (int c = 0; c < nc; ++c)
+        for (int j = 0; j < 10; ++j) {
+            const int o = 8 * c - 1 + j;
+            if (o < 0 || o >= L) continue;
+            const int p0 = j == 0 ? 0 : (j == 9 ? 2 : 1);
+            const int t_lo = c - 4 + p0;
+            for (int s = 0; s < l; ++s) {
+                const double v = K[(size_t)o * l + s];
+                if (v == 0.0) continue;
+                if (s < t_lo || s > t_lo + 6) return false;
+                const float fv = (float)v;
+                cw[(size_t)c * 72 + j * 7 + (s - t_lo)] = fv;
+                if (j >= 1 && j <= 8) {
+                    float* b = &bw[(size_t)c * 8 + (s - t_lo)];
+                    if (fabsf(fv) > *b) *b = fabsf(fv);
+                }
+            }
+        }
+    reg.assign(nc, 0);
+    if (interior)
+        for (int c = 0; c < nc; ++c) reg[c] = memcmp(&cw[(size_t)c * 72], interior, sizeof(float) * 70) == 0;
+    return true;
+}
+
+// The interior weights, from a map large enough to have cells away from every border;
+// uploaded to constant memory once per device.
+static int interior_weights(pd_ctx* ctx, const float** out) {
+    static std::mutex mu;
+    static float wts[72];
+    static bool have = false;
+    static bool uploaded[64];
+    std::lock_guard<std::mutex> lock(mu);
+    if (!have) {
+        const int l = 32, L = 256;
+        std::vector<int32_t> ofs(L), reg;
+        std::vector<float> coef(4 * (size_t)L), cw, bw;
+        std::vector<double> K;
+        pd_host_cubic_table(l, L, 0.125, ofs.data(), coef.data());
+        composite(L, l, ofs.data(), coef.data(), K);
+        if (!cell_weights(L, l, K, cw, bw, reg, nullptr)) return PD_E_STATE;
+        memset(wts, 0, sizeof(wts));
+        memcpy(wts, &cw[(size_t)16 * 72], sizeof(float) * 70);
+        if (memcmp(&cw[(size_t)15 * 72], wts, sizeof(float) * 70) != 0) return PD_E_STATE;
+        have = true;
+    }
+    const int dev = ctx->cfg.device_id;
+    if (dev < 0 || dev >= 64) return PD_E_STATE;
+    if (!uploaded[dev]) {
+        PD_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_kf_interior), wts, sizeof(wts)));
+        uploaded[dev] = true;
+    }
+    *out = wts;
+    return PD_OK;
+}
+
 static int build_filter_tables(pd_ctx* ctx) {
     const int h = ctx->h, w = ctx->w, H = ctx->H, W = ctx->W;
     if (ctx->kf_h == h && ctx->kf_w == w && ctx->kf_H == H && ctx->kf_W == W) return ctx->kf_ok ? PD_OK : PD_E_STATE;
@@ -65,8 +159,10 @@ static int build_filter_tables(pd_ctx* ctx) {
     ctx->kf_H = H;
     ctx->kf_W = W;
     ctx->kf_ok = 0;
-    const int wg = (W + 7) / 8;
-    if (h < 8 || w < 8 || H >= 65536 || W >= 65536 || wg > KF_NT) return PD_E_STATE;
+    const int hc = (H + 7) / 8, wc = (W + 7) / 8;
+    // cell coordinates are packed in 7 bits each; the active-cell kernel keeps one
+    // plane (h x w) and its row sums (h x wc) in LDS
+    if (h < 8 || w < 8 || hc > 128 || wc > 128 || (size_t)h * w + (size_t)h * wc > 15000) return PD_E_STATE;
     std::vector<int32_t> yofs(H), xofs(W);
     std::vector<float> yc(4 * (size_t)H), xc(4 * (size_t)W);
     pd_host_cubic_table(h, H, 0.125, yofs.data(), yc.data());
@@ -74,63 +170,37 @@ static int build_filter_tables(pd_ctx* ctx) {
     std::vector<double> Ky, Kx;
     composite(H, h, yofs.data(), yc.data(), Ky);
     composite(W, w, xofs.data(), xc.data(), Kx);
-    std::vector<int32_t> ystart(H);
-    std::vector<float> ycoef(8 * (size_t)H);
-    for (int Y = 0; Y < H; ++Y) {
-        int lo = h, hi = -1;
-        for (int s = 0; s < h; ++s)
-            if (Ky[(size_t)Y * h + s] != 0.0) {
-                if (s < lo) lo = s;
-                hi = s;
-            }
-        int st = lo < h - 8 ? lo : h - 8;
-        if (st < 0) st = 0;
-        if (hi - st > 7) return PD_E_STATE;
-        if (Y > 0 && st < ystart[Y - 1]) return PD_E_STATE;  // the band loader assumes monotone starts
-        ystart[Y] = st;
-        for (int k = 0; k < 8; ++k) ycoef[8 * (size_t)Y + k] = (float)Ky[(size_t)Y * h + st + k];
-    }
-    std::vector<float> xcoef((size_t)wg * 70, 0.f);
-    for (int g = 0; g < wg; ++g)
-        for (int jj = 0; jj < 10; ++jj) {
-            const int X = 8 * g + jj - 1;
-            if (X < 0 || X >= W) continue;
-            const int p0 = jj == 0 ? 0 : (jj == 9 ? 2 : 1);
-            const int t_lo = g - 4 + p0;
-            for (int t = 0; t < w; ++t) {
-                const double v = Kx[(size_t)X * w + t];
-                if (v == 0.0) continue;
-                if (t < t_lo || t > t_lo + 6) return PD_E_STATE;
-                xcoef[((size_t)jj * 7 + (t - t_lo)) * wg + g] = (float)v;  // [70][wg]: lane g reads coalesced
-            }
-        }
+    std::vector<float> cy, cx, by, bx;
+    std::vector<int32_t> ry, rx;
+    const float* interior = nullptr;
+    int rc = interior_weights(ctx, &interior);
+    if (rc != PD_OK) return rc;
+    if (!cell_weights(H, h, Ky, cy, by, ry, interior) || !cell_weights(W, w, Kx, cx, bx, rx, interior)) return PD_E_STATE;
+    // device layout: [hc][72] | [wc][72] | [hc][8] | [wc][8] floats, [hc] | [wc] flags
+    std::vector<float> tab;
+    tab.insert(tab.end(), cy.begin(), cy.end());
+    tab.insert(tab.end(), cx.begin(), cx.end());
+    tab.insert(tab.end(), by.begin(), by.end());
+    tab.insert(tab.end(), bx.begin(), bx.end());
+    std::vector<int32_t> reg(ry);
+    reg.insert(reg.end(), rx.begin(), rx.end());
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->kf_ycap < (size_t)H) {
-        if (ctx->kf_ystart) PD_HIP(ctx, hipFree(ctx->kf_ystart));
-        if (ctx->kf_ycoef) PD_HIP(ctx, hipFree(ctx->kf_ycoef));
-        ctx->kf_ystart = nullptr;
-        ctx->kf_ycoef = nullptr;
-        ctx->kf_ycap = 0;
-        PD_HIP(ctx, hipMalloc(&ctx->kf_ystart, sizeof(int32_t) * H));
-        PD_HIP(ctx, hipMalloc(&ctx->kf_ycoef, sizeof(float) * 8 * H));
-        ctx->kf_ycap = H;
+    if (ctx->kf_tab_cap < tab.size()) {
+        if (ctx->kf_tab) PD_HIP(ctx, hipFree(ctx->kf_tab));
+        ctx->kf_tab = nullptr;
+        ctx->kf_tab_cap = 0;
+        PD_HIP(ctx, hipMalloc(&ctx->kf_tab, sizeof(float) * tab.size()));
+        ctx->kf_tab_cap = tab.size();
     }
-    if (ctx->kf_xcap < (size_t)wg) {
-        if (ctx->kf_xcoef) PD_HIP(ctx, hipFree(ctx->kf_xcoef));
-        ctx->kf_xcoef = nullptr;
-        ctx->kf_xcap = 0;
-        PD_HIP(ctx, hipMalloc(&ctx->kf_xcoef, sizeof(float) * 70 * wg));
-        ctx->kf_xcap = wg;
+    if (ctx->kf_reg_cap < reg.size()) {
+        if (ctx->kf_reg) PD_HIP(ctx, hipFree(ctx->kf_reg));
+        ctx->kf_reg = nullptr;
+        ctx->kf_reg_cap = 0;
+        PD_HIP(ctx, hipMalloc(&ctx->kf_reg, sizeof(int32_t) * reg.size()));
+        ctx->kf_reg_cap = reg.size();
     }
-    {
-        int32_t* hcopy = (int32_t*)realloc(ctx->kf_ystart_host, sizeof(int32_t) * H);
-        if (!hcopy) return PD_E_STATE;
-        memcpy(hcopy, ystart.data(), sizeof(int32_t) * H);
-        ctx->kf_ystart_host = hcopy;
-    }
-    PD_HIP(ctx, hipMemcpy(ctx->kf_ystart, ystart.data(), sizeof(int32_t) * H, hipMemcpyHostToDevice));
-    PD_HIP(ctx, hipMemcpy(ctx->kf_ycoef, ycoef.data(), sizeof(float) * 8 * H, hipMemcpyHostToDevice));
-    PD_HIP(ctx, hipMemcpy(ctx->kf_xcoef, xcoef.data(), sizeof(float) * 70 * wg, hipMemcpyHostToDevice));
+    PD_HIP(ctx, hipMemcpy(ctx->kf_tab, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
+    PD_HIP(ctx, hipMemcpy(ctx->kf_reg, reg.data(), sizeof(int32_t) * reg.size(), hipMemcpyHostToDevice));
     ctx->kf_ok = 1;
     return PD_OK;
 }
@@ -165,210 +235,298 @@ k_heat_planar(const float* __restrict__ lo, int npix, float* __restrict__ planar
         for (int i = tid; i < np; i += 256) dst[(size_t)c * npix + i] = tile[i * PD_CH_HEAT + c];
 }
 
-struct FilterArgs {
+// Lower threshold and neighbour slack of the candidate test for an image whose
+// heatmaps are bounded by absmax.
+__device__ __forceinline__ void filter_slack(double thr, float absmax, float* thr_lo, float* e2) {
+    const double eps = ldexp((double)absmax, -17);
+    *thr_lo = nextafterf((float)(thr - eps), -INFINITY);
+    *e2 = nextafterf((float)(2.0 * eps), INFINITY);
+}
+
+// ---------------------------------------------------------------------------------
+// Active cells: one workgroup per (part, image) plane.
+// ---------------------------------------------------------------------------------
+struct CellArgs {
     const float* lo;  // planar copy (B, 19, h, w)
-    int h, w, H, W, wg;
-    int RL, RB, BH, src_rows;  // row lanes, rows per lane, band height, source rows staged per band
-    const int32_t* ystart;
-    const float* ycoef;
-    const float* xcoef;
+    int h, w, hc, wc;
+    const float* by;  // [hc][8] bound weights, sources y-3 .. y+3
+    const float* bx;  // [wc][8]
+    const int32_t* regy;
+    const int32_t* regx;
     const float* absmax;  // [B]
+    float2* slack;        // [B] out: (thr_lo, e2) of the candidate test
     double thr;
-    int2* cand;            // (plane, y << 16 | x), all planes in one list
-    int32_t* cand_count;   // [B][18] candidates seen per plane (may exceed CK)
-    int32_t* cand_total;   // entries in cand
-    int CK;
-    int band_sb0[KF_MAX_BANDS];  // first source row staged for each band
-    int band_ns[KF_MAX_BANDS];   // number of source rows staged
+    int32_t* cells;       // KF_NSEG segments; interior-weight cells from the front of a segment, the others from its back
+    int seg_cap;
+    int32_t* n_reg;       // [KF_NSEG]
+    int32_t* n_edge;      // [KF_NSEG]
 };
 
-// One workgroup per (row band, part, image).
-__global__ void __launch_bounds__(KF_NT)
-k_prefilter(FilterArgs a) {
+__global__ void __launch_bounds__(256)
+k_cells(CellArgs a) {
     extern __shared__ __align__(16) float lds[];
+    __shared__ int s_nr, s_ne, s_br, s_be;
     const int tid = threadIdx.x;
-    const int band = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
+    const int part = blockIdx.x, b = blockIdx.y;
+    const int plane = b * PD_N_PARTS + part;
+    const int h = a.h, w = a.w, hc = a.hc, wc = a.wc;
+    float* A = lds;                       // [h][w] |src|, later the list of active cells
+    float* V = A + (size_t)h * w;         // [h][wc] row sums
+    float* bxL = V + (size_t)h * wc;      // [8][wc]: lanes with consecutive x read consecutive words
+    float* byL = bxL + (size_t)8 * wc;    // [hc][8]
+    int* regL = (int*)(byL + (size_t)8 * hc);  // [hc] | [wc]
+    const float* img = a.lo + ((size_t)b * PD_CH_HEAT + part) * h * w;
+    if (tid == 0) {
+        s_nr = 0;
+        s_ne = 0;
+    }
+    for (int i = tid; i < h * w; i += 256) A[i] = fabsf(img[i]);
+    for (int i = tid; i < 8 * wc; i += 256) bxL[(i & 7) * wc + (i >> 3)] = a.bx[i];
+    for (int i = tid; i < 8 * hc; i += 256) byL[i] = a.by[i];
+    for (int i = tid; i < hc; i += 256) regL[i] = a.regy[i];
+    for (int i = tid; i < wc; i += 256) regL[hc + i] = a.regx[i];
+    float thr_lo, e2;
+    filter_slack(a.thr, a.absmax[b], &thr_lo, &e2);
+    if (part == 0 && tid == 0) a.slack[b] = make_float2(thr_lo, e2);
+    __syncthreads();
+    for (int i = tid; i < h * wc; i += 256) {
+        const int s = i / wc, x = i - s * wc;
+        const float* row = A + (size_t)s * w;
+        const float* k = bxL + x;
+        float v = k[0] * row[pd_clampi(x - 3, 0, w - 1)];
+#pragma unroll
+        for (int p = 1; p < 7; ++p) v = fmaf(k[p * wc], row[pd_clampi(x - 3 + p, 0, w - 1)], v);
+        V[i] = v;
+    }
+    __syncthreads();
+    int* list = (int*)A;  // hc * wc <= h * w entries
+    for (int i = tid; i < hc * wc; i += 256) {
+        const int y = i / wc, x = i - y * wc;
+        const float* k = byL + 8 * y;
+        float u = k[0] * V[(size_t)pd_clampi(y - 3, 0, h - 1) * wc + x];
+#pragma unroll
+        for (int p = 1; p < 7; ++p) u = fmaf(k[p], V[(size_t)pd_clampi(y - 3 + p, 0, h - 1) * wc + x], u);
+        if (u * 1.00001f >= thr_lo) {  // the factor covers the rounding of the chains on both sides
+            const int entry = (plane << 14) | (y << 7) | x;
+            if (regL[y] & regL[hc + x])
+                list[atomicAdd(&s_nr, 1)] = entry;
+            else
+                list[hc * wc - 1 - atomicAdd(&s_ne, 1)] = entry;
+        }
+    }
+    __syncthreads();
+    const int nr = s_nr, ne = s_ne;
+    const int seg = plane % KF_NSEG;
+    if (tid == 0) {
+        s_br = nr ? atomicAdd(a.n_reg + seg, nr) : 0;
+        s_be = ne ? atomicAdd(a.n_edge + seg, ne) : 0;
+    }
+    __syncthreads();
+    // every cell is listed at most once and a segment has room for all cells of its planes
+    int32_t* segment = a.cells + (size_t)seg * a.seg_cap;
+    for (int i = tid; i < nr; i += 256) segment[s_br + i] = list[i];
+    for (int i = tid; i < ne; i += 256) segment[a.seg_cap - 1 - (s_be + i)] = list[hc * wc - 1 - i];
+}
+
+// ---------------------------------------------------------------------------------
+// Candidate filter over the listed cells.
+// ---------------------------------------------------------------------------------
+struct CellFilterArgs {
+    const float* lo;  // planar copy (B, 19, h, w)
+    int h, w, H, W;
+    const float* cy;  // [hc][72]
+    const float* cx;  // [wc][72]
+    const float2* slack;   // [B] (thr_lo, e2)
+    const int32_t* cells;
+    int seg_cap;
+    const int32_t* n_reg;
+    const int32_t* n_edge;
+    int2* cand;            // (plane, y << 16 | x), KF_NSEG segments
+    int cand_seg_cap;
+    int32_t* cand_count;   // [B][18] candidates seen per plane (may exceed CK)
+    int32_t* cand_n;       // [KF_NSEG] entries asked for per segment (may exceed cand_seg_cap)
+    int CK;
+};
+
+// Exclusive prefix of the segment counts (each clipped to the segment capacity) into
+// pref[0 .. KF_NSEG]; call with all threads, ends with a barrier.
+__device__ __forceinline__ void segment_prefix(const int32_t* counts, int seg_cap, int* pref, int tid) {
+    if (tid < 64) {
+        int c = tid < KF_NSEG ? min(counts[tid], seg_cap) : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < KF_NSEG; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (tid >= d) incl += o;
+        }
+        if (tid < KF_NSEG) pref[tid + 1] = incl;
+        if (tid == 0) pref[0] = 0;
+    }
+    __syncthreads();
+}
+
+// Global index -> position in the segmented array (segment * seg_cap + offset).
+__device__ __forceinline__ int segment_locate(const int* pref, int seg_cap, int gi) {
+    int seg = 0;
+#pragma unroll
+    for (int d = KF_NSEG / 2; d >= 1; d >>= 1)
+        if (pref[seg + d] <= gi) seg += d;
+    return seg * seg_cap + (gi - pref[seg]);
+}
+
+struct FilterShared {
+    float tile[KF_CELLS_PER_BLOCK][9][10];  // per cell: x-pass sums, source row q, output column i
+    int2 cand[KF_LCAND];
+    int pref[KF_NSEG + 1];
+    int n_cand;
+    int base;
+};
+
+// Staged candidates -> the global list.  Entries beyond the list's capacity mark their
+// plane as overflowing instead (the exact kernel then redoes it).
+__device__ __forceinline__ void flush_candidates(const CellFilterArgs& a, FilterShared& sh, int tid) {
+    const int n = min(sh.n_cand, KF_LCAND);
+    if (n > 0) {
+        const int seg = blockIdx.x % KF_NSEG;
+        if (tid == 0) sh.base = atomicAdd(a.cand_n + seg, n);
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int idx = sh.base + i;
+            if (idx < a.cand_seg_cap)
+                a.cand[(size_t)seg * a.cand_seg_cap + idx] = sh.cand[i];
+            else
+                atomicOr(a.cand_count + sh.cand[i].x, KF_OVERFLOW);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) sh.n_cand = 0;
+    __syncthreads();
+}
+
+// REG: all cells of the list carry the interior weights, which then come from the
+// kernel arguments (scalar registers); otherwise each lane loads its cell's weights.
+template <bool REG>
+__device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShared& sh, int n_cells, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int cs = lane / 10, r = lane - cs * 10;
+    const int slot = wv * KF_CELLS_PER_WAVE + (cs < KF_CELLS_PER_WAVE ? cs : 0);
     const int h = a.h, w = a.w, H = a.H, W = a.W;
-    const int Yb = band * a.BH;               // first row this band decides
-    const int nrowsT = a.BH + 2;              // rows Yb-1 .. Yb+BH
-    const int tw = w + 8;                     // T row: 4 zero pads each side
-    float* kcL = lds;                                     // [BH+2][8] row-pass coefficients
-    int* ysL = (int*)(lds + (size_t)nrowsT * 8);          // [BH+2] window starts (relative)
-    float* srcL = lds + (size_t)nrowsT * 9;               // [src_rows + 8][w]
-    float* T = srcL + (size_t)(a.src_rows + 8) * w;       // [BH+2][w+8]
-    const float* img = a.lo + ((size_t)b * PD_CH_HEAT + part) * h * w;  // planar (B, 19, h, w)
-
-    // Everything this band reads from memory is requested at once: its source rows,
-    // and the row-pass coefficients and window starts of its BH + 2 rows (contiguous in
-    // the tables), so the row pass below runs out of LDS with no dependent loads.
-    const int sb0 = a.band_sb0[band], ns = a.band_ns[band];
-    for (int i = tid; i < ns * w; i += KF_NT) srcL[i] = img[(size_t)sb0 * w + i];
-    for (int i = tid; i < 8 * w; i += KF_NT) srcL[ns * w + i] = 0.f;  // rows past the range meet zero coefficients
-    for (int i = tid; i < nrowsT * 8; i += KF_NT) {
-        const int Y = Yb - 1 + (i >> 3);
-        kcL[i] = (Y >= 0 && Y < H) ? a.ycoef[8 * (size_t)Y + (i & 7)] : 0.f;
-    }
-    for (int i = tid; i < nrowsT; i += KF_NT) {
-        const int Y = Yb - 1 + i;
-        ysL[i] = (Y >= 0 && Y < H) ? a.ystart[Y] - sb0 : 0;
-    }
-    __syncthreads();
-
-    // rows: T[Yr][t], Yr = Y - (Yb - 1).  A thread owns one source column t and a run
-    // of consecutive rows: the eight source values of its window stay in registers and
-    // are re-read only when the window start moves (once per 8 rows)
-    for (int i = tid; i < nrowsT * 8; i += KF_NT) {  // zero pads left and right of each T row
-        const int r = i >> 3, p = i & 7;
-        T[(size_t)r * tw + (p < 4 ? p : w + p)] = 0.f;
-    }
-    {
-        const int n_chunks = KF_NT / w;  // w <= 256 is guaranteed by the table builder
-        const int col = tid % w, chunk = tid / w;
-        if (chunk < n_chunks) {
-            const int per = (nrowsT + n_chunks - 1) / n_chunks;
-            const int r_lo = chunk * per, r_hi = min(nrowsT, r_lo + per);
-            int cur = -1;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-            for (int r = r_lo; r < r_hi; ++r) {
-                const int y0 = ysL[r];
-                if (y0 != cur) {
-                    const float* sp = srcL + (size_t)y0 * w + col;
-                    s0 = sp[0];
-                    s1 = sp[w];
-                    s2 = sp[2 * w];
-                    s3 = sp[3 * w];
-                    s4 = sp[4 * w];
-                    s5 = sp[5 * w];
-                    s6 = sp[6 * w];
-                    s7 = sp[7 * w];
-                    cur = y0;
+    for (int base = blockIdx.x * KF_CELLS_PER_BLOCK; base < n_cells; base += gridDim.x * KF_CELLS_PER_BLOCK) {
+        const int ci = base + wv * KF_CELLS_PER_WAVE + cs;
+        const bool act = cs < KF_CELLS_PER_WAVE && ci < n_cells;
+        int plane = 0, y = 0, x = 0;
+        float thr_lo = 0.f, e2 = 0.f;
+        if (act) {
+            const int at = segment_locate(sh.pref, a.seg_cap, ci);  // segment * seg_cap + offset
+            const int e = a.cells[REG ? at : at - 2 * (at % a.seg_cap) + a.seg_cap - 1];
+            plane = e >> 14;
+            y = (e >> 7) & 127;
+            x = e & 127;
+            const float2 sl = a.slack[plane / PD_N_PARTS];
+            thr_lo = sl.x;
+            e2 = sl.y;
+        }
+        // x pass: lane r < 9 owns source row y-4+r and forms the ten column sums
+        if (act && r < 9) {
+            const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
+            const float* row = a.lo + (((size_t)b * PD_CH_HEAT + part) * h + pd_clampi(y - 4 + r, 0, h - 1)) * w;
+            float v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) v[c] = row[pd_clampi(x - 4 + c, 0, w - 1)];
+            float k[72];
+            if (!REG) {
+                const float4* kq = (const float4*)(a.cx + (size_t)x * 72);
+#pragma unroll
+                for (int q = 0; q < 18; ++q) {
+                    const float4 t = kq[q];
+                    k[4 * q] = t.x;
+                    k[4 * q + 1] = t.y;
+                    k[4 * q + 2] = t.z;
+                    k[4 * q + 3] = t.w;
                 }
-                const float4 ka = *(const float4*)(kcL + 8 * r), kb = *(const float4*)(kcL + 8 * r + 4);
-                float v = ka.x * s0;
-                v = fmaf(ka.y, s1, v);
-                v = fmaf(ka.z, s2, v);
-                v = fmaf(ka.w, s3, v);
-                v = fmaf(kb.x, s4, v);
-                v = fmaf(kb.y, s5, v);
-                v = fmaf(kb.z, s6, v);
-                v = fmaf(kb.w, s7, v);
-                T[(size_t)r * tw + col + 4] = v;  // rows outside the image have zero coefficients: T = 0
             }
-        }
-    }
-    __syncthreads();
-
-    // columns + tolerant NMS: thread = (column group g, row lane rl)
-    const int g = tid % a.wg, rl = tid / a.wg;
-    if (rl >= a.RL) return;
-    // coefficients: the eight real columns as four pairs for packed FMAs (all use
-    // window positions 1..7), the two halo columns (positions 0..6 and 2..8) scalar
-    float2v kp[4][7];
-    float kl[7], kr[7];
+            float* out = &sh.tile[slot][r][0];
 #pragma unroll
-    for (int p = 0; p < 7; ++p) {
-        kl[p] = a.xcoef[(size_t)(0 * 7 + p) * a.wg + g];
-        kr[p] = a.xcoef[(size_t)(9 * 7 + p) * a.wg + g];
+            for (int half = 0; half < 2; ++half) {
+                const ConstF* kp = fresh_pointer(c_kf_interior);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            kp[q][p].x = a.xcoef[(size_t)((2 * q + 1) * 7 + p) * a.wg + g];
-            kp[q][p].y = a.xcoef[(size_t)((2 * q + 2) * 7 + p) * a.wg + g];
-        }
-    }
-    const double eps = ldexp((double)a.absmax[b], -17);
-    const float thr_lo = nextafterf((float)(a.thr - eps), -INFINITY);
-    const float e2 = nextafterf((float)(2.0 * eps), INFINITY);
-    float prev1[10], prev2[8];
+                for (int i = 5 * half; i < 5 * half + 5; ++i) {
+                    const int p0 = i == 0 ? 0 : (i == 9 ? 2 : 1);
+                    float s = (REG ? kp[7 * i] : k[7 * i]) * v[p0];
 #pragma unroll
-    for (int j = 0; j < 10; ++j) prev1[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) prev2[j] = 0.f;
-    const int Y0 = Yb + rl * a.RB;  // first row this thread decides
-    int32_t* plane_count = a.cand_count + b * PD_N_PARTS + part;
-    for (int it = 0; it < a.RB + 2; ++it) {
-        const int Y = Y0 - 1 + it;  // row being evaluated; row Y - 1 is decided
-        const float* tp = T + (size_t)(Y - (Yb - 1)) * tw + g;
-        float t[9];
-#pragma unroll
-        for (int p = 0; p < 9; ++p) t[p] = tp[p];
-        float cur[10];
-        // |S~| <= 1.375 * max |T| over the window (sum of |Kx| per column <= 1.375): where
-        // that is below the threshold for the whole wavefront the ten sums are skipped and
-        // zeros stand in -- such pixels cannot be candidates, and as neighbours of a
-        // candidate (which is > thr_lo > 0) a zero passes exactly when the true value would
-        float tmax = fabsf(t[0]);
-#pragma unroll
-        for (int p = 1; p < 9; ++p) tmax = fmaxf(tmax, fabsf(t[p]));
-        if (__ballot(1.376f * tmax >= thr_lo) == 0ull) {
-#pragma unroll
-            for (int j = 0; j < 10; ++j) cur[j] = 0.f;
-        } else {
-            float2v acc[4];
-            float hl = kl[0] * t[0], hr = kr[0] * t[2];
-            {
-                const float2v tt = {t[1], t[1]};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = kp[q][0] * tt;
-            }
-#pragma unroll
-            for (int p = 1; p < 7; ++p) {
-                const float2v tt = {t[1 + p], t[1 + p]};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_elementwise_fma(kp[q][p], tt, acc[q]);
-                hl = fmaf(kl[p], t[p], hl);
-                hr = fmaf(kr[p], t[2 + p], hr);
-            }
-            cur[0] = hl;
-            cur[9] = hr;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                cur[2 * q + 1] = acc[q].x;
-                cur[2 * q + 2] = acc[q].y;
-            }
-        }
-        const int Yc = Y - 1;
-        if (it >= 2 && Yc < H) {
-            // most rows hold nothing above the threshold: one max + ballot skips them
-            float mx = prev1[1];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, prev1[j + 1]);
-            if (__ballot(mx > thr_lo) != 0ull) {
-                // branch-free test of the eight pixels: q >= 0 iff the pixel passes
-                // (c >= n - e2 is tested as c + e2 >= n; the half-ulp rounding of that sum,
-                // 6e-8 |c|, is far inside the slack between eps and the error bound)
-                float best = -1.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float c = prev1[j + 1];
-                    const float m4 = fmaxf(fmaxf(prev2[j], cur[j + 1]), fmaxf(prev1[j], prev1[j + 2]));
-                    best = fmaxf(best, fminf(c - thr_lo, (c + e2) - m4));
-                }
-                if (best >= 0.f) {  // rare: some pixel of this thread's eight may be a candidate
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float c = prev1[j + 1];
-                        const float ce = c + e2;
-                        const int X = 8 * g + j;
-                        const bool ok = X < W && c > thr_lo && ce >= prev2[j] && ce >= cur[j + 1] &&
-                                        ce >= prev1[j] && ce >= prev1[j + 2];
-                        if (ok) {
-                            // the per-plane count decides overflow, the list itself is one
-                            // global array so the verification is balanced over the chip
-                            const int pos = atomicAdd(plane_count, 1);
-                            if (pos < a.CK) {
-                                const int gi = atomicAdd(a.cand_total, 1);
-                                a.cand[gi] = make_int2(b * PD_N_PARTS + part, (Yc << 16) | X);
-                            }
-                        }
-                    }
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * i + p] : k[7 * i + p], v[p0 + p], s);
+                    out[i] = s;
                 }
             }
         }
+        __syncthreads();
+        // y pass: lane r owns output column 8x-1+r and forms its ten row sums
+        float S[10];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) prev2[j] = prev1[j + 1];
+        for (int j = 0; j < 10; ++j) S[j] = 0.f;
+        if (act) {
+            float t[9];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) prev1[j] = cur[j];
+            for (int q = 0; q < 9; ++q) t[q] = sh.tile[slot][q][r];
+            float k[72];
+            if (!REG) {
+                const float4* kq = (const float4*)(a.cy + (size_t)y * 72);
+#pragma unroll
+                for (int q = 0; q < 18; ++q) {
+                    const float4 u = kq[q];
+                    k[4 * q] = u.x;
+                    k[4 * q + 1] = u.y;
+                    k[4 * q + 2] = u.z;
+                    k[4 * q + 3] = u.w;
+                }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const ConstF* kp = fresh_pointer(c_kf_interior);
+#pragma unroll
+                for (int j = 5 * half; j < 5 * half + 5; ++j) {
+                    const int p0 = j == 0 ? 0 : (j == 9 ? 2 : 1);
+                    float s = (REG ? kp[7 * j] : k[7 * j]) * t[p0];
+#pragma unroll
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * j + p] : k[7 * j + p], t[p0 + p], s);
+                    S[j] = s;
+                }
+            }
+        }
+        // tolerant NMS of the cell's own 8 x 8 pixels (rows j = 1..8 of lanes r = 1..8);
+        // sums of outputs outside the map are zero, like the reference's zero border
+        const int X = 8 * x - 1 + r;
+        const bool own = act && r >= 1 && r <= 8 && X < W;
+#pragma unroll
+        for (int j = 1; j <= 8; ++j) {
+            const float c = S[j];
+            const float left = __shfl_up(c, 1), right = __shfl_down(c, 1);
+            const float ce = c + e2;
+            const int Y = 8 * y - 1 + j;
+            const bool ok = own && Y < H && c > thr_lo && ce >= S[j - 1] && ce >= S[j + 1] && ce >= left && ce >= right;
+            if (ok) {
+                atomicAdd(a.cand_count + plane, 1);
+                const int pos = atomicAdd(&sh.n_cand, 1);
+                if (pos < KF_LCAND)
+                    sh.cand[pos] = make_int2(plane, (Y << 16) | X);
+                else
+                    atomicOr(a.cand_count + plane, KF_OVERFLOW);  // no room: leave the plane to the exact kernel
+            }
+        }
+        __syncthreads();
+        if (sh.n_cand > KF_LCAND / 2) flush_candidates(a, sh, tid);
     }
+}
+
+template <bool REG>
+__global__ void __launch_bounds__(256)
+k_cell_filter(CellFilterArgs a) {
+    __shared__ FilterShared sh;
+    const int tid = threadIdx.x;
+    if (tid == 0) sh.n_cand = 0;
+    segment_prefix(REG ? a.n_reg : a.n_edge, a.seg_cap, sh.pref, tid);
+    filter_cells<REG>(a, sh, sh.pref[KF_NSEG], tid);
+    flush_candidates(a, sh, tid);
 }
 
 struct VerifyArgs {
@@ -377,8 +535,9 @@ struct VerifyArgs {
     Up8 up8;
     double thr;
     const int2* cand;
+    int cand_seg_cap;
     const int32_t* cand_count;
-    const int32_t* cand_total;
+    const int32_t* cand_n;
     int CK;
     RawPeak* raw;
     int32_t* raw_count;
@@ -395,19 +554,23 @@ k_verify(VerifyArgs a) {
     __shared__ double ypL[8][3][28];
     __shared__ float hvL[8][256];
     __shared__ float4 s_up[8];
+    __shared__ int s_pref[KF_NSEG + 1];
     const int tid = threadIdx.x;
     const int half = tid >> 5, l = tid & 31;
-    if (tid < 8) s_up[tid] = make_float4(a.up8.c[tid][0], a.up8.c[tid][1], a.up8.c[tid][2], a.up8.c[tid][3]);
-    const int total = *a.cand_total;
+    if (tid >= 64 && tid < 72) {
+        const int p = tid - 64;
+        s_up[p] = make_float4(a.up8.c[p][0], a.up8.c[p][1], a.up8.c[p][2], a.up8.c[p][3]);
+    }
+    segment_prefix(a.cand_n, a.cand_seg_cap, s_pref, tid);
+    const int total = s_pref[KF_NSEG];
     const int H = a.H, W = a.W, h = a.h, w = a.w;
-    __syncthreads();
     for (int base = blockIdx.x * 8; base < total; base += gridDim.x * 8) {
         const int ci = base + half;
         bool active = ci < total;
         int Y = 0, X = 0, plane = 0;
         double u13 = 0.0;
         if (active) {
-            const int2 e = a.cand[ci];
+            const int2 e = a.cand[segment_locate(s_pref, a.cand_seg_cap, ci)];
             plane = e.x;
             Y = e.y >> 16;
             X = e.y & 0xffff;
@@ -488,11 +651,25 @@ k_verify(VerifyArgs a) {
     }
 }
 
+static int grow(pd_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
+    if (*cap >= need_bytes) return PD_OK;
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*p) PD_HIP(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    PD_HIP(ctx, hipMalloc(p, need_bytes));
+    *cap = need_bytes;
+    return PD_OK;
+}
+
 int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     int rc = build_filter_tables(ctx);
     if (rc != PD_OK) return rc;
     const int B = ctx->B, H = ctx->H, W = ctx->W, h = ctx->h, w = ctx->w;
+    const int hc = (H + 7) / 8, wc = (W + 7) / 8;
     const int CK = 4 * ctx->cfg.max_peaks_per_part;
+    const size_t planes_max = (size_t)ctx->cfg.max_batch * PD_N_PARTS;
+    if (planes_max >= (1u << 17)) return PD_E_STATE;  // plane index is packed in 17 bits
     if (!ctx->cand || ctx->cand_cap != CK) {
         PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->cand) PD_HIP(ctx, hipFree(ctx->cand));
@@ -501,85 +678,80 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         ctx->cand = nullptr;
         ctx->cand_count = nullptr;
         ctx->absmax = nullptr;
-        PD_HIP(ctx, hipMalloc(&ctx->cand, sizeof(int2) * (size_t)ctx->cfg.max_batch * PD_N_PARTS * CK));
-        PD_HIP(ctx, hipMalloc(&ctx->cand_count, sizeof(int32_t) * ((size_t)ctx->cfg.max_batch * PD_N_PARTS + 1)));
-        PD_HIP(ctx, hipMalloc(&ctx->absmax, sizeof(float) * (size_t)ctx->cfg.max_batch));
+        PD_HIP(ctx, hipMalloc(&ctx->cand, sizeof(int2) * planes_max * CK));
+        PD_HIP(ctx, hipMalloc(&ctx->cand_count, sizeof(int32_t) * (planes_max + 3 * KF_NSEG)));
+        PD_HIP(ctx, hipMalloc(&ctx->absmax, sizeof(float) * 3 * (size_t)ctx->cfg.max_batch));  // max |v| | (thr_lo, e2)
         ctx->cand_cap = CK;
     }
-    {
-        const size_t need = sizeof(float) * (size_t)B * PD_CH_HEAT * h * w;
-        if (ctx->heat_planar_cap < need) {
-            PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->heat_planar) PD_HIP(ctx, hipFree(ctx->heat_planar));
-            ctx->heat_planar = nullptr;
-            ctx->heat_planar_cap = 0;
-            PD_HIP(ctx, hipMalloc(&ctx->heat_planar, need));
-            ctx->heat_planar_cap = need;
-        }
-    }
-    FilterArgs f;
+    rc = grow(ctx, (void**)&ctx->heat_planar, &ctx->heat_planar_cap, sizeof(float) * (size_t)B * PD_CH_HEAT * h * w);
+    if (rc != PD_OK) return rc;
+    const size_t planes = (size_t)B * PD_N_PARTS;
+    const size_t n_cells_max = planes * hc * wc;
+    // a segment holds the cells of the planes p with p % KF_NSEG == its index
+    const size_t seg_cap = ((planes + KF_NSEG - 1) / KF_NSEG) * hc * wc;
+    rc = grow(ctx, (void**)&ctx->cells, &ctx->cells_cap, sizeof(int32_t) * seg_cap * KF_NSEG);
+    if (rc != PD_OK) return rc;
+    // counters behind the per-plane candidate counts, KF_NSEG each: candidates, interior cells, border cells
+    int32_t* counters = ctx->cand_count + planes;
+    const float* tab = ctx->kf_tab;
+
+    CellArgs c;
+    c.lo = ctx->heat_planar;
+    c.h = h;
+    c.w = w;
+    c.hc = hc;
+    c.wc = wc;
+    c.by = tab + (size_t)72 * (hc + wc);
+    c.bx = c.by + (size_t)8 * hc;
+    c.regy = ctx->kf_reg;
+    c.regx = ctx->kf_reg + hc;
+    c.absmax = ctx->absmax;
+    c.slack = (float2*)(ctx->absmax + ctx->cfg.max_batch);
+    c.thr = thr;
+    c.cells = ctx->cells;
+    c.seg_cap = (int)seg_cap;
+    c.n_reg = counters + KF_NSEG;
+    c.n_edge = counters + 2 * KF_NSEG;
+
+    CellFilterArgs f;
     f.lo = ctx->heat_planar;
     f.h = h;
     f.w = w;
     f.H = H;
     f.W = W;
-    f.wg = (W + 7) / 8;
-    f.RL = KF_NT / f.wg;
-    // rows per thread: the choice that wastes the fewest row evaluations (each thread
-    // evaluates RB + 2 rows, bands are RL * RB rows) within the LDS budget
-    int best_rb = 0;
-    long best_cost = 0;
-    for (int rb = 8; rb <= 64; ++rb) {
-        const int bh = f.RL * rb;
-        const long lds_b = 4L * ((long)(bh + 2) * 9 + ((bh + 26) / 8 + 17) * w + (long)(bh + 2) * (w + 8));
-        if (lds_b > 40000) break;
-        const long cost = (long)((H + bh - 1) / bh) * f.RL * (rb + 2);
-        if (best_rb == 0 || cost < best_cost) {
-            best_rb = rb;
-            best_cost = cost;
-        }
-    }
-    if (best_rb == 0) return PD_E_STATE;
-    f.RB = best_rb;
-    f.BH = f.RL * f.RB;
-    f.src_rows = (f.BH + 26) / 8 + 9;
-    if (f.src_rows > h) f.src_rows = h;
-    f.ystart = ctx->kf_ystart;
-    f.ycoef = ctx->kf_ycoef;
-    f.xcoef = ctx->kf_xcoef;
-    f.absmax = ctx->absmax;
-    f.thr = thr;
+    f.cy = tab;
+    f.cx = tab + (size_t)72 * hc;
+    f.slack = (const float2*)(ctx->absmax + ctx->cfg.max_batch);
+    f.cells = ctx->cells;
+    f.seg_cap = c.seg_cap;
+    f.n_reg = c.n_reg;
+    f.n_edge = c.n_edge;
     f.cand = (int2*)ctx->cand;
+    f.cand_seg_cap = (int)(planes * CK / KF_NSEG);
     f.cand_count = ctx->cand_count;
-    f.cand_total = ctx->cand_count + (size_t)B * PD_N_PARTS;  // one more counter behind the planes'
+    f.cand_n = counters;
     f.CK = CK;
-    const int nbands = (H + f.BH - 1) / f.BH;
-    if (nbands > KF_MAX_BANDS) return PD_E_STATE;
-    for (int band = 0; band < nbands; ++band) {
-        const int Yb = band * f.BH;
-        const int Ylo = Yb - 1 < 0 ? 0 : Yb - 1;
-        const int Yhi = Yb + f.BH > H - 1 ? H - 1 : Yb + f.BH;
-        const int sb0 = ctx->kf_ystart_host[Ylo];
-        int sb1 = ctx->kf_ystart_host[Yhi] + 7;
-        if (sb1 > h - 1) sb1 = h - 1;
-        int ns = sb1 - sb0 + 1;
-        if (ns > f.src_rows) return PD_E_STATE;
-        f.band_sb0[band] = sb0;
-        f.band_ns[band] = ns;
-    }
-    // LDS: coefficients + starts (9 per row), source rows (+8 zero rows), T rows
-    const size_t lds = sizeof(float) * ((size_t)(f.BH + 2) * 9 + (size_t)(f.src_rows + 8) * w + (size_t)(f.BH + 2) * (w + 8));
-    if (lds > 64000) return PD_E_STATE;
-    PD_HIP(ctx, hipMemsetAsync(ctx->cand_count, 0, sizeof(int32_t) * ((size_t)B * PD_N_PARTS + 1), ctx->stream));
+
+    PD_HIP(ctx, hipMemsetAsync(ctx->cand_count, 0, sizeof(int32_t) * (planes + 3 * KF_NSEG), ctx->stream));
     PD_HIP(ctx, hipMemsetAsync(ctx->absmax, 0, sizeof(float) * B, ctx->stream));
     pd_prof_begin(ctx, PD_STAGE_PLANAR);
     hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
                        h * w, ctx->heat_planar, (unsigned int*)ctx->absmax);
     pd_prof_end(ctx);
+    pd_prof_begin(ctx, PD_STAGE_CELLS);
+    hipLaunchKernelGGL(k_cells, dim3(PD_N_PARTS, B), dim3(256),
+                       sizeof(float) * ((size_t)h * w + (size_t)h * wc + 9 * (size_t)(hc + wc)), ctx->stream, c);
+    pd_prof_end(ctx);
+    // the list lengths are only known on the device: fixed grids stride over them
+    size_t fblocks = (n_cells_max / 8 + KF_CELLS_PER_BLOCK - 1) / KF_CELLS_PER_BLOCK;
+    if (fblocks > 2048) fblocks = 2048;
+    if (fblocks < 1) fblocks = 1;
     pd_prof_begin(ctx, PD_STAGE_FILTER);
-    hipLaunchKernelGGL(k_prefilter, dim3(nbands, PD_N_PARTS, B), dim3(KF_NT), lds, ctx->stream, f);
+    hipLaunchKernelGGL(k_cell_filter<true>, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, f);
+    hipLaunchKernelGGL(k_cell_filter<false>, dim3((unsigned)((fblocks + 3) / 4)), dim3(256), 0, ctx->stream, f);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
+
     VerifyArgs v;
     v.lo = ctx->heat_planar;
     v.h = h;
@@ -589,13 +761,13 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     pd_up8_fill(&v.up8);
     v.thr = thr;
     v.cand = (const int2*)ctx->cand;
+    v.cand_seg_cap = f.cand_seg_cap;
     v.cand_count = ctx->cand_count;
-    v.cand_total = f.cand_total;
+    v.cand_n = counters;
     v.CK = CK;
     v.raw = ctx->raw;
     v.raw_count = ctx->raw_count;
     v.PK = ctx->cfg.max_peaks_per_part;
-    // the list length is only known on the device: a fixed grid strides over it
     int vblocks = B * 12;
     if (vblocks > 1024) vblocks = 1024;
     pd_prof_begin(ctx, PD_STAGE_VERIFY);
