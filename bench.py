@@ -33,14 +33,14 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='b64_368', choices=sorted(WORKLOADS))
     ap.add_argument('--mode', default='D', choices=['P', 'D'])
     ap.add_argument('--cpu-images', type=int, default=12, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--people', type=int, default=0, help='experiments: fixed people per image')
-    ap.add_argument('--contexts', type=int, default=2, help='decode contexts (HIP streams) per GPU in ping-pong')
+    ap.add_argument('--contexts', type=int, default=3, help='decode contexts (HIP streams) per GPU, used round-robin')
     args = ap.parse_args()
 
     import torch
@@ -68,8 +68,9 @@ def main():
     d_paf = torch.from_numpy(paf).cuda()
     torch.cuda.synchronize()
 
-    # two contexts (two HIP streams) in ping-pong: while the skeletons of batch i are
-    # copied out and gathered, the kernels of batch i+1 already run
+    # several contexts (one HIP stream each) used round-robin: while the skeletons of
+    # batch i are copied out and gathered, the kernels of the next batches already run,
+    # and the short kernels of different batches overlap on the chip
     engs = [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=local_rank,
                          max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000)
             for _ in range(args.contexts)]
@@ -103,15 +104,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Timed region: only the roofline kernel carries an event pair (one pair per step);
+    # timing every kernel would put two dozen event records between the kernels of
+    # every step and slow the job down by a third.  The full per-stage breakdown comes
+    # from a separate, untimed pass afterwards.
+    ROOF_STAGE = 'filter'
+    for e in engs:
+        e.ctx.profile(stages=[ROOF_STAGE])
+    run(3 * len(engs))     # every context reaches its captured launch graph (third identical call)
     last = run(args.warmup)
     for e in engs:
-        e.ctx.profile(True)
+        e.ctx.profile_read()
     barrier()
     t0 = time.perf_counter()
     last = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    roof_ms, roof_n = 0.0, 0
+    for e in engs:
+        v = e.ctx.profile_read()[ROOF_STAGE]
+        roof_ms += v[0]
+        roof_n += v[1]
     prof = {}
+    stage_steps = max(10, min(50, args.steps))
+    for e in engs:
+        e.ctx.profile(True)
+    run(3 * len(engs))
+    for e in engs:
+        e.ctx.profile_read()
+    run(stage_steps)
     for e in engs:
         for k, v in e.ctx.profile_read().items():
             a = prof.get(k, (0.0, 0))
@@ -126,14 +147,19 @@ def main():
     if rank == 0:
         images = world * B * args.steps
         n, N = h * w, H * W
-        # dominant kernel: the peak stage's pass over every pixel of the 18 part
-        # channels (upsample x8 + Gaussian + NMS in one kernel: k_prefilter, or
-        # k_smooth_nms_stream when the exact kernel runs alone).  Algorithmic bytes per
-        # image of that stage: upsample read 18*n*4 + write 18*N*4, Gaussian read +
-        # write 2*18*N*4, NMS read 18*N*4  =  72*n + 288*N.
-        kname, kstage = ('k_prefilter', 'filter') if prof.get('filter', (0, 0))[1] else \
-            ('k_smooth_nms_stream', 'smooth_nms')
-        sm_ms, sm_n = prof[kstage]
+        # Roofline kernel: k_cell_filter<true>, the float32 evaluation of the smoothed x8 map
+        # and its non-maximum suppression (with k_cells, which picks the 8x8 cells it has
+        # to visit, it stands for the reference's upsample + Gaussian + NMS pass over every
+        # pixel of the 18 part channels).  Algorithmic bytes per image of that pass:
+        # upsample read 18*n*4 + write 18*N*4, Gaussian read + write 2*18*N*4, NMS read
+        # 18*N*4  =  72*n + 288*N.  The kernel itself touches a few percent of that, so the
+        # fraction says how much faster than a materialising implementation at HBM peak
+        # the stage runs, not how busy HBM is.
+        kname = 'k_cell_filter<true>'
+        sm_ms, sm_n = roof_ms, roof_n
+        if sm_n == 0:       # the exact streaming kernel ran alone (no filter tables for this geometry)
+            kname = 'k_smooth_nms_stream'
+            sm_ms, sm_n = prof['smooth_nms']
         alg_bytes = B * (72.0 * n + 288.0 * N)
         avg_s = (sm_ms / max(sm_n, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
@@ -159,7 +185,7 @@ def main():
                          'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': sm_n,
                          'algorithmic_bytes_per_launch': alg_bytes},
             'job_hbm_frac_per_gpu': (value / world) * job_bytes / 1e9 / HBM_PEAK_GBS,
-            'stage_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+            'stage_ms_per_launch_untimed_pass': {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
         res0 = last
         out['persons_last_step'] = int(res0['person_count'].sum())

@@ -185,13 +185,17 @@ enum {
     PD_STAGE_MATCH = 4,      /* per-limb sort + greedy matching */
     PD_STAGE_PARSE = 5,      /* person assembly */
     PD_STAGE_PACK = 6,       /* result packing */
-    PD_STAGE_FILTER = 7,     /* float32 composite-kernel candidate filter */
+    PD_STAGE_FILTER = 7,     /* float32 candidate filter over the active cells with interior weights */
     PD_STAGE_VERIFY = 8,     /* exact float64 verification of the candidates */
     PD_STAGE_PLANAR = 9,     /* (h, w, 19) -> planar copy of the heatmaps + max |v| */
     PD_STAGE_CELLS = 10,     /* active-cell scan at network resolution */
-    PD_N_STAGES = 11
+    PD_STAGE_FILTER_BORDER = 11, /* candidate filter over the cells with border weights */
+    PD_N_STAGES = 12
 };
 int pd_profile(pd_ctx* ctx, int enable);
+/* The same, restricted to the stages whose bit (1u << PD_STAGE_x) is set: timing one
+ * stage costs one event pair per launch instead of one per kernel. */
+int pd_profile_stages(pd_ctx* ctx, uint32_t stage_mask);
 int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);
 
 /* The smoothed heatmap the peak stage compares (scipy.ndimage.gaussian_filter,

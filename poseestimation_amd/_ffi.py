@@ -21,9 +21,9 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages']
 
-STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells']
+STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells', 'filter_border']
 
 
 class Config(C.Structure):
@@ -121,6 +121,7 @@ def lib():
     L.pd_packed_device.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.pd_results_host.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.pd_profile.argtypes = [vp, i32]
+    L.pd_profile_stages.argtypes = [vp, C.c_uint32]
     L.pd_filter_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
@@ -286,8 +287,15 @@ class Context:
                                    _ptr(out['conns']), _ptr(out['persons'])))
         return out
 
-    def profile(self, enable=True):
-        self.check(self.L.pd_profile(self._h, 1 if enable else 0))
+    def profile(self, enable=True, stages=None):
+        """Time every stage (enable=True), none, or only the named stages."""
+        if stages is not None:
+            mask = 0
+            for name in stages:
+                mask |= 1 << STAGES.index(name)
+            self.check(self.L.pd_profile_stages(self._h, mask))
+        else:
+            self.check(self.L.pd_profile(self._h, 1 if enable else 0))
 
     def profile_read(self):
         """{stage: (total_ms, launches)} since the last read (waits for the stream)."""

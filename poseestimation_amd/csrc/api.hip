@@ -679,7 +679,8 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
 }
 
 void pd_prof_begin(pd_ctx* ctx, int stage) {
-    if (!ctx->prof_on) return;
+    ctx->prof_open = 0;
+    if (!((ctx->prof_on >> stage) & 1)) return;
     if (ctx->prof_n == ctx->prof_cap) {
         const int ncap = ctx->prof_cap ? ctx->prof_cap * 2 : 256;
         hipEvent_t* ev = (hipEvent_t*)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * ncap);
@@ -693,17 +694,25 @@ void pd_prof_begin(pd_ctx* ctx, int stage) {
     }
     ctx->prof_stage[ctx->prof_n] = stage;
     (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], ctx->stream);
+    ctx->prof_open = 1;
 }
 
 void pd_prof_end(pd_ctx* ctx) {
-    if (!ctx->prof_on || ctx->prof_n >= ctx->prof_cap) return;
+    if (!ctx->prof_open || ctx->prof_n >= ctx->prof_cap) return;
     (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream);
     ++ctx->prof_n;
+    ctx->prof_open = 0;
 }
 
 extern "C" int pd_profile(pd_ctx* ctx, int enable) {
     PD_CHECK_CTX(ctx);
-    ctx->prof_on = enable != 0;
+    ctx->prof_on = enable ? ~0u : 0u;
+    return PD_OK;
+}
+
+extern "C" int pd_profile_stages(pd_ctx* ctx, uint32_t stage_mask) {
+    PD_CHECK_CTX(ctx);
+    ctx->prof_on = stage_mask;
     return PD_OK;
 }
 

@@ -86,7 +86,8 @@ struct GraphKey {
     const float* paf;
     int B, h, w, H, W;
     double t1, t2;
-    int mode, impl, prof;
+    int mode, impl;
+    uint32_t prof;
 };
 
 struct TableSlot {
@@ -170,7 +171,9 @@ struct pd_ctx {
     size_t res_cap, res_spec, res_have;
     int have_peaks, have_conns, have_persons, packed;
     // ---- stage timing (pd_profile) ----
-    int prof_on, prof_n, prof_cap;  // prof_n: pairs recorded since the last harvest
+    uint32_t prof_on;               // bit s set: stage s is timed
+    int prof_open;                  // a start event is waiting for its stop
+    int prof_n, prof_cap;           // prof_n: pairs recorded since the last harvest
     hipEvent_t* prof_ev;  // [2*i] start, [2*i+1] stop
     int* prof_stage;
     double prof_ms[PD_N_STAGES];

@@ -280,7 +280,20 @@ k_cells(CellArgs a) {
         s_nr = 0;
         s_ne = 0;
     }
-    for (int i = tid; i < h * w; i += 256) A[i] = fabsf(img[i]);
+    // all loads of a round are issued before the first value is used
+    for (int i0 = 0; i0 < h * w; i0 += 256 * 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * 256 + tid;
+            t[k] = i < h * w ? img[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * 256 + tid;
+            if (i < h * w) A[i] = fabsf(t[k]);
+        }
+    }
     for (int i = tid; i < 8 * wc; i += 256) bxL[(i & 7) * wc + (i >> 3)] = a.bx[i];
     for (int i = tid; i < 8 * hc; i += 256) byL[i] = a.by[i];
     for (int i = tid; i < hc; i += 256) regL[i] = a.regy[i];
@@ -289,29 +302,54 @@ k_cells(CellArgs a) {
     filter_slack(a.thr, a.absmax[b], &thr_lo, &e2);
     if (part == 0 && tid == 0) a.slack[b] = make_float2(thr_lo, e2);
     __syncthreads();
-    for (int i = tid; i < h * wc; i += 256) {
-        const int s = i / wc, x = i - s * wc;
-        const float* row = A + (size_t)s * w;
-        const float* k = bxL + x;
-        float v = k[0] * row[pd_clampi(x - 3, 0, w - 1)];
+    // thread = (cell column x, row lane): weights and clamped taps of the column stay in registers
+    const int lanes = 256 / wc;  // wc <= 128
+    const int x = tid % wc, rl = tid / wc;
+    if (rl < lanes) {
+        float k[7];
+        int c[7];
 #pragma unroll
-        for (int p = 1; p < 7; ++p) v = fmaf(k[p * wc], row[pd_clampi(x - 3 + p, 0, w - 1)], v);
-        V[i] = v;
+        for (int p = 0; p < 7; ++p) {
+            k[p] = bxL[p * wc + x];
+            c[p] = pd_clampi(x - 3 + p, 0, w - 1);
+        }
+        for (int s0 = rl; s0 < h; s0 += lanes) {
+            const float* row = A + (size_t)s0 * w;
+            float v = k[0] * row[c[0]];
+#pragma unroll
+            for (int p = 1; p < 7; ++p) v = fmaf(k[p], row[c[p]], v);
+            V[(size_t)s0 * wc + x] = v;
+        }
     }
     __syncthreads();
     int* list = (int*)A;  // hc * wc <= h * w entries
-    for (int i = tid; i < hc * wc; i += 256) {
-        const int y = i / wc, x = i - y * wc;
-        const float* k = byL + 8 * y;
-        float u = k[0] * V[(size_t)pd_clampi(y - 3, 0, h - 1) * wc + x];
+    if (rl < lanes) {
+        // a run of consecutive cell rows per thread, the seven row sums it needs sliding through registers
+        const int per = (hc + lanes - 1) / lanes;
+        const int y0 = rl * per, y1 = min(hc, y0 + per);
+        float win[7];
 #pragma unroll
-        for (int p = 1; p < 7; ++p) u = fmaf(k[p], V[(size_t)pd_clampi(y - 3 + p, 0, h - 1) * wc + x], u);
-        if (u * 1.00001f >= thr_lo) {  // the factor covers the rounding of the chains on both sides
-            const int entry = (plane << 14) | (y << 7) | x;
-            if (regL[y] & regL[hc + x])
-                list[atomicAdd(&s_nr, 1)] = entry;
-            else
-                list[hc * wc - 1 - atomicAdd(&s_ne, 1)] = entry;
+        for (int p = 0; p < 7; ++p) win[p] = V[(size_t)pd_clampi(y0 - 3 + p, 0, h - 1) * wc + x];
+        const int regx = regL[hc + x];
+        for (int y = y0; y < y1; ++y) {
+            const float4 ka = *(const float4*)(byL + 8 * y), kb = *(const float4*)(byL + 8 * y + 4);
+            float u = ka.x * win[0];
+            u = fmaf(ka.y, win[1], u);
+            u = fmaf(ka.z, win[2], u);
+            u = fmaf(ka.w, win[3], u);
+            u = fmaf(kb.x, win[4], u);
+            u = fmaf(kb.y, win[5], u);
+            u = fmaf(kb.z, win[6], u);
+            if (u * 1.00001f >= thr_lo) {  // the factor covers the rounding of the chains on both sides
+                const int entry = (plane << 14) | (y << 7) | x;
+                if (regL[y] & regx)
+                    list[atomicAdd(&s_nr, 1)] = entry;
+                else
+                    list[hc * wc - 1 - atomicAdd(&s_ne, 1)] = entry;
+            }
+#pragma unroll
+            for (int p = 0; p < 6; ++p) win[p] = win[p + 1];
+            win[6] = V[(size_t)pd_clampi(y + 4, 0, h - 1) * wc + x];
         }
     }
     __syncthreads();
@@ -377,65 +415,83 @@ __device__ __forceinline__ int segment_locate(const int* pref, int seg_cap, int 
 struct FilterShared {
     float tile[KF_CELLS_PER_BLOCK][9][10];  // per cell: x-pass sums, source row q, output column i
     int2 cand[KF_LCAND];
-    int pref[KF_NSEG + 1];
     int n_cand;
     int base;
 };
 
-// Staged candidates -> the global list.  Entries beyond the list's capacity mark their
-// plane as overflowing instead (the exact kernel then redoes it).
-__device__ __forceinline__ void flush_candidates(const CellFilterArgs& a, FilterShared& sh, int tid) {
-    const int n = min(sh.n_cand, KF_LCAND);
-    if (n > 0) {
-        const int seg = blockIdx.x % KF_NSEG;
-        if (tid == 0) sh.base = atomicAdd(a.cand_n + seg, n);
-        __syncthreads();
-        for (int i = tid; i < n; i += 256) {
-            const int idx = sh.base + i;
-            if (idx < a.cand_seg_cap)
-                a.cand[(size_t)seg * a.cand_seg_cap + idx] = sh.cand[i];
-            else
-                atomicOr(a.cand_count + sh.cand[i].x, KF_OVERFLOW);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) sh.n_cand = 0;
-    __syncthreads();
+// One cell of the list, decoded, with the nine source values of this lane's row.
+struct CellWork {
+    int plane, y, x;  // plane < 0: no cell
+    float thr_lo, e2;
+    float v[9];
+};
+
+__device__ __forceinline__ int load_entry(const int32_t* list, int n, int ci, bool lane_ok, bool reg, int seg_cap) {
+    if (!lane_ok || ci >= n) return -1;
+    return list[reg ? ci : seg_cap - 1 - ci];
 }
 
-// REG: all cells of the list carry the interior weights, which then come from the
-// kernel arguments (scalar registers); otherwise each lane loads its cell's weights.
+// Issues the loads of a cell: the (thr_lo, e2) pair of its image and, for lanes r < 9,
+// source row y-4+r at columns x-4 .. x+4 (clamped; taps outside the map have zero weight).
+__device__ __forceinline__ void load_cell(const CellFilterArgs& a, int e, int r, CellWork& c) {
+    c.plane = -1;
+    c.y = c.x = 0;
+    c.thr_lo = c.e2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c.v[k] = 0.f;
+    if (e < 0) return;
+    c.plane = e >> 14;
+    c.y = (e >> 7) & 127;
+    c.x = e & 127;
+    const int b = c.plane / PD_N_PARTS, part = c.plane - b * PD_N_PARTS;
+    const float2 sl = a.slack[b];
+    c.thr_lo = sl.x;
+    c.e2 = sl.y;
+    if (r < 9) {
+        const float* row = a.lo + (((size_t)b * PD_CH_HEAT + part) * a.h + pd_clampi(c.y - 4 + r, 0, a.h - 1)) * a.w;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c.v[k] = row[pd_clampi(c.x - 4 + k, 0, a.w - 1)];
+    }
+}
+
+// Workgroups of segment s = blockIdx.x % KF_NSEG share that segment's cells; every
+// wavefront takes six cells at a time (ten lanes per cell) and runs on its own: the
+// x-pass results cross lanes through a wave-private LDS tile, and the loads of the next
+// six cells are in flight while the current ones are evaluated.
+// REG: the cells carry the interior weights, which reach the multiply-adds as scalar
+// operands from constant memory; otherwise each lane loads its cell's weights.
 template <bool REG>
-__device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShared& sh, int n_cells, int tid) {
+__global__ void __launch_bounds__(256)
+k_cell_filter(CellFilterArgs a) {
+    __shared__ FilterShared sh;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int cs = lane / 10, r = lane - cs * 10;
-    const int slot = wv * KF_CELLS_PER_WAVE + (cs < KF_CELLS_PER_WAVE ? cs : 0);
-    const int h = a.h, w = a.w, H = a.H, W = a.W;
-    for (int base = blockIdx.x * KF_CELLS_PER_BLOCK; base < n_cells; base += gridDim.x * KF_CELLS_PER_BLOCK) {
-        const int ci = base + wv * KF_CELLS_PER_WAVE + cs;
-        const bool act = cs < KF_CELLS_PER_WAVE && ci < n_cells;
-        int plane = 0, y = 0, x = 0;
-        float thr_lo = 0.f, e2 = 0.f;
-        if (act) {
-            const int at = segment_locate(sh.pref, a.seg_cap, ci);  // segment * seg_cap + offset
-            const int e = a.cells[REG ? at : at - 2 * (at % a.seg_cap) + a.seg_cap - 1];
-            plane = e >> 14;
-            y = (e >> 7) & 127;
-            x = e & 127;
-            const float2 sl = a.slack[plane / PD_N_PARTS];
-            thr_lo = sl.x;
-            e2 = sl.y;
-        }
+    const bool lane_ok = cs < KF_CELLS_PER_WAVE;
+    const int slot = wv * KF_CELLS_PER_WAVE + (lane_ok ? cs : 0);
+    const int H = a.H, W = a.W;
+    const int seg = blockIdx.x % KF_NSEG;
+    const int wave_id = (blockIdx.x / KF_NSEG) * 4 + wv;       // within the segment
+    const int n_waves = (gridDim.x / KF_NSEG) * 4;             // the grid is a multiple of KF_NSEG
+    const int n = min((REG ? a.n_reg : a.n_edge)[seg], a.seg_cap);
+    const int32_t* list = a.cells + (size_t)seg * a.seg_cap;
+    if (tid == 0) sh.n_cand = 0;
+    __syncthreads();
+
+    const int stride = n_waves * KF_CELLS_PER_WAVE;
+    int base = wave_id * KF_CELLS_PER_WAVE;  // first cell of this wavefront's current six
+    CellWork cur, nxt;
+    load_cell(a, load_entry(list, n, base + cs, lane_ok, REG, a.seg_cap), r, cur);
+    int e_next = load_entry(list, n, base + stride + cs, lane_ok, REG, a.seg_cap);
+    while (base < n) {
+        load_cell(a, e_next, r, nxt);
+        e_next = load_entry(list, n, base + 2 * stride + cs, lane_ok, REG, a.seg_cap);
+        const bool act = cur.plane >= 0;
         // x pass: lane r < 9 owns source row y-4+r and forms the ten column sums
         if (act && r < 9) {
-            const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
-            const float* row = a.lo + (((size_t)b * PD_CH_HEAT + part) * h + pd_clampi(y - 4 + r, 0, h - 1)) * w;
-            float v[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) v[c] = row[pd_clampi(x - 4 + c, 0, w - 1)];
             float k[72];
             if (!REG) {
-                const float4* kq = (const float4*)(a.cx + (size_t)x * 72);
+                const float4* kq = (const float4*)(a.cx + (size_t)cur.x * 72);
 #pragma unroll
                 for (int q = 0; q < 18; ++q) {
                     const float4 t = kq[q];
@@ -452,14 +508,15 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
 #pragma unroll
                 for (int i = 5 * half; i < 5 * half + 5; ++i) {
                     const int p0 = i == 0 ? 0 : (i == 9 ? 2 : 1);
-                    float s = (REG ? kp[7 * i] : k[7 * i]) * v[p0];
+                    float s = (REG ? kp[7 * i] : k[7 * i]) * cur.v[p0];
 #pragma unroll
-                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * i + p] : k[7 * i + p], v[p0 + p], s);
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * i + p] : k[7 * i + p], cur.v[p0 + p], s);
                     out[i] = s;
                 }
             }
         }
-        __syncthreads();
+        // the tile is private to this wavefront, whose LDS accesses complete in order
+        __builtin_amdgcn_wave_barrier();
         // y pass: lane r owns output column 8x-1+r and forms its ten row sums
         float S[10];
 #pragma unroll
@@ -470,7 +527,7 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
             for (int q = 0; q < 9; ++q) t[q] = sh.tile[slot][q][r];
             float k[72];
             if (!REG) {
-                const float4* kq = (const float4*)(a.cy + (size_t)y * 72);
+                const float4* kq = (const float4*)(a.cy + (size_t)cur.y * 72);
 #pragma unroll
                 for (int q = 0; q < 18; ++q) {
                     const float4 u = kq[q];
@@ -493,40 +550,44 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
         // tolerant NMS of the cell's own 8 x 8 pixels (rows j = 1..8 of lanes r = 1..8);
         // sums of outputs outside the map are zero, like the reference's zero border
-        const int X = 8 * x - 1 + r;
+        const int X = 8 * cur.x - 1 + r;
         const bool own = act && r >= 1 && r <= 8 && X < W;
 #pragma unroll
         for (int j = 1; j <= 8; ++j) {
             const float c = S[j];
             const float left = __shfl_up(c, 1), right = __shfl_down(c, 1);
-            const float ce = c + e2;
-            const int Y = 8 * y - 1 + j;
-            const bool ok = own && Y < H && c > thr_lo && ce >= S[j - 1] && ce >= S[j + 1] && ce >= left && ce >= right;
+            const float ce = c + cur.e2;
+            const int Y = 8 * cur.y - 1 + j;
+            const bool ok = own && Y < H && c > cur.thr_lo && ce >= S[j - 1] && ce >= S[j + 1] && ce >= left && ce >= right;
             if (ok) {
-                atomicAdd(a.cand_count + plane, 1);
+                atomicAdd(a.cand_count + cur.plane, 1);
                 const int pos = atomicAdd(&sh.n_cand, 1);
                 if (pos < KF_LCAND)
-                    sh.cand[pos] = make_int2(plane, (Y << 16) | X);
+                    sh.cand[pos] = make_int2(cur.plane, (Y << 16) | X);
                 else
-                    atomicOr(a.cand_count + plane, KF_OVERFLOW);  // no room: leave the plane to the exact kernel
+                    atomicOr(a.cand_count + cur.plane, KF_OVERFLOW);  // no room: leave the plane to the exact kernel
             }
         }
-        __syncthreads();
-        if (sh.n_cand > KF_LCAND / 2) flush_candidates(a, sh, tid);
+        cur = nxt;
+        base += stride;
     }
-}
-
-template <bool REG>
-__global__ void __launch_bounds__(256)
-k_cell_filter(CellFilterArgs a) {
-    __shared__ FilterShared sh;
-    const int tid = threadIdx.x;
-    if (tid == 0) sh.n_cand = 0;
-    segment_prefix(REG ? a.n_reg : a.n_edge, a.seg_cap, sh.pref, tid);
-    filter_cells<REG>(a, sh, sh.pref[KF_NSEG], tid);
-    flush_candidates(a, sh, tid);
+    // staged candidates -> this segment of the global list; entries beyond its capacity
+    // mark their plane as overflowing instead (the exact kernel then redoes it)
+    __syncthreads();
+    const int nc = min(sh.n_cand, KF_LCAND);
+    if (nc == 0) return;
+    if (tid == 0) sh.base = atomicAdd(a.cand_n + seg, nc);
+    __syncthreads();
+    for (int i = tid; i < nc; i += 256) {
+        const int idx = sh.base + i;
+        if (idx < a.cand_seg_cap)
+            a.cand[(size_t)seg * a.cand_seg_cap + idx] = sh.cand[i];
+        else
+            atomicOr(a.cand_count + sh.cand[i].x, KF_OVERFLOW);
+    }
 }
 
 struct VerifyArgs {
@@ -745,10 +806,13 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     // the list lengths are only known on the device: fixed grids stride over them
     size_t fblocks = (n_cells_max / 8 + KF_CELLS_PER_BLOCK - 1) / KF_CELLS_PER_BLOCK;
     if (fblocks > 2048) fblocks = 2048;
-    if (fblocks < 1) fblocks = 1;
+    fblocks = (fblocks + KF_NSEG - 1) / KF_NSEG * KF_NSEG;  // whole workgroups per segment
     pd_prof_begin(ctx, PD_STAGE_FILTER);
     hipLaunchKernelGGL(k_cell_filter<true>, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, f);
-    hipLaunchKernelGGL(k_cell_filter<false>, dim3((unsigned)((fblocks + 3) / 4)), dim3(256), 0, ctx->stream, f);
+    pd_prof_end(ctx);
+    pd_prof_begin(ctx, PD_STAGE_FILTER_BORDER);
+    hipLaunchKernelGGL(k_cell_filter<false>, dim3((unsigned)((fblocks / 4 + KF_NSEG - 1) / KF_NSEG * KF_NSEG)), dim3(256), 0,
+                       ctx->stream, f);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
 
