@@ -167,7 +167,7 @@ def main():
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.workload)
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                traffic = json.load(f).get('smooth_nms_hbm_bytes_per_launch')
+                traffic = json.load(f).get('roofline_kernel_hbm_bytes_per_launch')
         # the whole decode against the whole-path byte count per image:
         # 228*n + 228*N + 216*N (+ 80 bytes per candidate pair, not counted here)
         job_bytes = 228.0 * n + 444.0 * N
