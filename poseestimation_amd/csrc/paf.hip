@@ -10,6 +10,7 @@
 // Candidates are taken in descending score order, ties in a-major / b-minor order
 // (stable sort, :141), a peak being used at most once per side (:144-156).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -27,6 +28,7 @@ struct PairArgs {
     int max_pairs;
     double* pair_score;
     int32_t* status;
+    int per_image;  // workgroups per image
 };
 
 // Two adjacent channels (ch, ch+1) of a (h, w, C) float32 map, bicubic at (Y, X);
@@ -60,15 +62,36 @@ __device__ __forceinline__ void bicubic2_at(const float* __restrict__ img, int h
     *o1 = ((h1[0] * bc.x + h1[1] * bc.y) + h1[2] * bc.z) + h1[3] * bc.w;
 }
 
-// 16 lanes per candidate pair: lanes 0..9 take one sample point each, then the ten
-// products are summed in sample order.
+// What the ten sample lanes of a pair need, computed once per pair.
+struct PairGeo {
+    double u0, u1;   // unit vector components paired with channels 2k and 2k+1
+    double sy, sx;   // linspace steps
+    double prior;    // min(0.5 * H / norm - 1, 0)
+    int ya, xa, yb, xb;
+    int k;           // limb, or -1: the pair is skipped (coincident peaks in mode P) or absent
+    int pad;
+};
+
+#define PAIRS_PER_CHUNK 6   // pairs a wavefront takes at a time: 6 lanes x 1 pair, then 6 pairs x 10 samples
+
+// Every wavefront works on its own: lanes 0..5 first derive the geometry of six pairs,
+// then ten lanes per pair take one sample point each, and lane 0 of each group adds the
+// ten products in sample order.  The kernel is bound by the latency of the sample
+// gathers (every tap of every sample is a cache line of its own in the (h, w, 38)
+// layout), so a wavefront takes few pairs and many wavefronts are in flight.
+// The grid is one-dimensional and swizzled so that the workgroups of one image run on
+// one XCD (workgroup i goes to XCD i % 8) and its PAF map stays in that XCD's L2.
 __global__ void __launch_bounds__(256)
 k_pair_scores(PairArgs a) {
     __shared__ int32_t s_off[PD_N_LIMBS + 1];
     __shared__ int32_t s_cnt[PD_N_PARTS];
     __shared__ float4 s_up[8];
-    const int b = blockIdx.y;
+    __shared__ PairGeo s_geo[4][PAIRS_PER_CHUNK];
+    __shared__ double s_mid[4][6][10];
     const int tid = threadIdx.x;
+    const int per_xcd = gridDim.x / 8;  // the grid is a multiple of 8 workgroups
+    const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int b = logical / a.per_image, blk = logical - b * a.per_image;
     if (tid >= 64 && tid < 72) {
         const float* c = a.src.up8.c[tid - 64];
         s_up[tid - 64] = make_float4(c[0], c[1], c[2], c[3]);
@@ -78,52 +101,79 @@ k_pair_scores(PairArgs a) {
     __syncthreads();
     const int total = s_off[PD_N_LIMBS];
     if (total < 0) {  // more candidate pairs than the context was sized for
-        if (tid == 0 && blockIdx.x == 0) a.status[b] = PD_E_OVERFLOW;
+        if (tid == 0 && blk == 0) a.status[b] = PD_E_OVERFLOW;
         return;
     }
-    const int group = tid >> 4;
-    const int i = tid & 15;
-    const int lane = tid & 63;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int cs = lane / 10, i = lane - cs * 10;  // sample phase: group and sample index
     const int H = a.src.H, W = a.src.W;
     const size_t npx = (size_t)H * W;
-    for (int base = blockIdx.x * 16; base < total; base += gridDim.x * 16) {
-        const int p = base + group;
-        const bool active = p < total;
-        double mid = 0.0, u0 = 0.0, u1 = 0.0, norm = 1.0;
-        bool skip = true;
-        if (active) {
-            int k = 0;
-            while (p >= s_off[k + 1]) ++k;
-            const int pa = pd_limb_from(k), pb = pd_limb_to(k);
-            const int nB = s_cnt[pb];
-            const int local = p - s_off[k];
-            const int ia = local / nB, ib = local - ia * nB;
-            const size_t oa = ((size_t)b * PD_N_PARTS + pa) * a.PK + ia;
-            const size_t ob = ((size_t)b * PD_N_PARTS + pb) * a.PK + ib;
-            const int ya = a.pk_y[oa], xa = a.pk_x[oa], yb = a.pk_y[ob], xb = a.pk_x[ob];
-            const long long dy = (long long)yb - ya, dx = (long long)xb - xa;
-            const double d2 = (double)(dy * dy + dx * dx);
-            norm = sqrt(d2);
-            double uy, ux;
-            if (a.mode == PD_MODE_P) {
-                skip = d2 == 0.0;  // coincident peaks, utils/postprocess.py:112
-                uy = (double)dy / norm;
-                ux = (double)dx / norm;
-            } else {
-                skip = false;
-                norm = fmax(norm, 1e-5);  // predict.py:141
-                uy = (double)dy / norm;
-                ux = (double)dx / norm;
+    const int n_waves = a.per_image * 4;
+    PairGeo* geo = s_geo[wv];
+    for (int base = (blk * 4 + wv) * PAIRS_PER_CHUNK; base < total; base += n_waves * PAIRS_PER_CHUNK) {
+        // ---- geometry: lane = pair ----
+        if (lane < PAIRS_PER_CHUNK) {
+            const int p = base + lane;
+            PairGeo g;
+            g.k = -1;
+            g.u0 = g.u1 = g.sy = g.sx = g.prior = 0.0;
+            g.ya = g.xa = g.yb = g.xb = g.pad = 0;
+            if (p < total) {
+                int k = 0;
+#pragma unroll
+                for (int d = 16; d >= 1; d >>= 1)
+                    if (k + d <= PD_N_LIMBS - 1 && s_off[k + d] <= p) k += d;
+                const int pa = pd_limb_from(k), pb = pd_limb_to(k);
+                const int nB = s_cnt[pb];
+                const int local = p - s_off[k];
+                const int ia = local / nB, ib = local - ia * nB;
+                const size_t oa = ((size_t)b * PD_N_PARTS + pa) * a.PK + ia;
+                const size_t ob = ((size_t)b * PD_N_PARTS + pb) * a.PK + ib;
+                g.ya = a.pk_y[oa];
+                g.xa = a.pk_x[oa];
+                g.yb = a.pk_y[ob];
+                g.xb = a.pk_x[ob];
+                const long long dy = (long long)g.yb - g.ya, dx = (long long)g.xb - g.xa;
+                const double d2 = (double)(dy * dy + dx * dx);
+                double norm = sqrt(d2);
+                bool skip = false;
+                if (a.mode == PD_MODE_P)
+                    skip = d2 == 0.0;  // coincident peaks, utils/postprocess.py:112
+                else
+                    norm = fmax(norm, 1e-5);  // predict.py:141
+                const double uy = (double)dy / norm, ux = (double)dx / norm;
+                if (a.mode == PD_MODE_P) {  // channel 2k pairs with dy, 2k+1 with dx
+                    g.u0 = uy;
+                    g.u1 = ux;
+                } else {                    // channel 2k pairs with dx, 2k+1 with dy
+                    g.u0 = ux;
+                    g.u1 = uy;
+                }
+                g.sy = (double)dy / 9.0;
+                g.sx = (double)dx / 9.0;
+                g.prior = fmin(0.5 * (double)H / norm - 1.0, 0.0);
+                g.k = skip ? -1 : k;
+                if (skip) a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
             }
-            if (!skip && i < PD_MID) {
+            geo[lane] = g;
+        }
+        __builtin_amdgcn_wave_barrier();  // the staging area is private to this wavefront
+        // ---- samples: ten lanes per pair, six pairs per pass ----
+        for (int pass = 0; pass < PAIRS_PER_CHUNK / 6; ++pass) {
+            const int q = pass * 6 + cs;
+            const bool act = cs < 6 && base + q < total;
+            double mid = 0.0;
+            int k = -1;
+            if (act) k = geo[q].k;
+            if (k >= 0) {
+                const PairGeo g = geo[q];
                 double py, px;
                 if (i == PD_MID - 1) {
-                    py = (double)yb;
-                    px = (double)xb;
+                    py = (double)g.yb;
+                    px = (double)g.xb;
                 } else {
-                    const double sy = (double)dy / 9.0, sx = (double)dx / 9.0;
-                    py = (double)i * sy + (double)ya;
-                    px = (double)i * sx + (double)xa;
+                    py = (double)i * g.sy + (double)g.ya;
+                    px = (double)i * g.sx + (double)g.xa;
                 }
                 int iy, ix;
                 if (a.mode == PD_MODE_P) {
@@ -147,31 +197,24 @@ k_pair_scores(PairArgs a) {
                     v0 = pl[0];
                     v1 = pl[npx];
                 }
-                if (a.mode == PD_MODE_P) {  // channel 2k pairs with dy, 2k+1 with dx
-                    u0 = uy;
-                    u1 = ux;
-                } else {                    // channel 2k pairs with dx, 2k+1 with dy
-                    u0 = ux;
-                    u1 = uy;
-                }
-                mid = v0 * u0 + v1 * u1;
+                mid = v0 * g.u0 + v1 * g.u1;
             }
-        }
-        // sequential sum over the ten samples of this group, as builtin sum() does
-        const int g0 = lane & 48;
-        double acc = 0.0 + __shfl(mid, g0);
+            if (cs < 6) s_mid[wv][cs][i] = mid;
+            __builtin_amdgcn_wave_barrier();
+            if (k >= 0 && i == 0) {
+                // sequential sum over the ten samples, as builtin sum() does
+                const double* m = s_mid[wv][cs];
+                double acc = 0.0 + m[0];
+                int n_above = m[0] > a.thr;
 #pragma unroll
-        for (int s = 1; s < PD_MID; ++s) acc = acc + __shfl(mid, g0 + s);
-        const unsigned long long above = __ballot(i < PD_MID && mid > a.thr);
-        const int n_above = __builtin_popcountll((above >> g0) & 0xFFFFull);
-        if (active && i == 0) {
-            double out = -1.0;
-            if (!skip) {
-                const double prior = fmin(0.5 * (double)H / norm - 1.0, 0.0);
-                const double score = acc / 10.0 + prior;
-                if (n_above > 8 && score > 0.0) out = score;
+                for (int s2 = 1; s2 < PD_MID; ++s2) {
+                    acc = acc + m[s2];
+                    n_above += m[s2] > a.thr;
+                }
+                const double score = acc / 10.0 + geo[q].prior;
+                a.pair_score[(size_t)b * a.max_pairs + base + q] = (n_above > 8 && score > 0.0) ? score : -1.0;
             }
-            a.pair_score[(size_t)b * a.max_pairs + p] = out;
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -365,10 +408,13 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     a.max_pairs = ctx->cfg.max_pairs_per_image;
     a.pair_score = ctx->pair_score;
     a.status = ctx->status;
-    int per_image = (ctx->cfg.max_pairs_per_image + 15) / 16;
+    // 4 wavefronts per workgroup, 60 pairs per wavefront pass
+    int per_image = (ctx->cfg.max_pairs_per_image + 4 * PAIRS_PER_CHUNK - 1) / (4 * PAIRS_PER_CHUNK);
     if (per_image > 64) per_image = 64;
+    per_image = (per_image + 7) / 8 * 8;  // the XCD swizzle needs a grid that is a multiple of 8
+    a.per_image = per_image;
     pd_prof_begin(ctx, PD_STAGE_PAIRS);
-    hipLaunchKernelGGL(k_pair_scores, dim3(per_image, ctx->B), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_pair_scores, dim3(per_image * ctx->B), dim3(256), 0, ctx->stream, a);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
