@@ -116,7 +116,8 @@ static bool cell_weights(int L, int l, const std::vector<double>& K, std::vector
         }
     reg.assign(nc, 0);
     if (interior)
-        for (int c = 0; c < nc; ++c) reg[c] = memcmp(&cw[(size_t)c * 72], interior, sizeof(float) * 70) == 0;
+        for (int c = 0; c < nc; ++c)
+            reg[c] = c - 4 >= 0 && c + 4 <= l - 1 && memcmp(&cw[(size_t)c * 72], interior, sizeof(float) * 70) == 0;
     return true;
 }
 
@@ -433,6 +434,7 @@ __device__ __forceinline__ int load_entry(const int32_t* list, int n, int ci, bo
 
 // Issues the loads of a cell: the (thr_lo, e2) pair of its image and, for lanes r < 9,
 // source row y-4+r at columns x-4 .. x+4 (clamped; taps outside the map have zero weight).
+template <bool REG>
 __device__ __forceinline__ void load_cell(const CellFilterArgs& a, int e, int r, CellWork& c) {
     c.plane = -1;
     c.y = c.x = 0;
@@ -448,9 +450,15 @@ __device__ __forceinline__ void load_cell(const CellFilterArgs& a, int e, int r,
     c.thr_lo = sl.x;
     c.e2 = sl.y;
     if (r < 9) {
-        const float* row = a.lo + (((size_t)b * PD_CH_HEAT + part) * a.h + pd_clampi(c.y - 4 + r, 0, a.h - 1)) * a.w;
+        if (REG) {  // the 9 x 9 source window of a cell with interior weights lies inside the map
+            const float* p = a.lo + (((size_t)b * PD_CH_HEAT + part) * a.h + (c.y - 4 + r)) * a.w + (c.x - 4);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) c.v[k] = row[pd_clampi(c.x - 4 + k, 0, a.w - 1)];
+            for (int k = 0; k < 9; ++k) c.v[k] = p[k];
+        } else {
+            const float* row = a.lo + (((size_t)b * PD_CH_HEAT + part) * a.h + pd_clampi(c.y - 4 + r, 0, a.h - 1)) * a.w;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) c.v[k] = row[pd_clampi(c.x - 4 + k, 0, a.w - 1)];
+        }
     }
 }
 
@@ -481,10 +489,10 @@ k_cell_filter(CellFilterArgs a) {
     const int stride = n_waves * KF_CELLS_PER_WAVE;
     int base = wave_id * KF_CELLS_PER_WAVE;  // first cell of this wavefront's current six
     CellWork cur, nxt;
-    load_cell(a, load_entry(list, n, base + cs, lane_ok, REG, a.seg_cap), r, cur);
+    load_cell<REG>(a, load_entry(list, n, base + cs, lane_ok, REG, a.seg_cap), r, cur);
     int e_next = load_entry(list, n, base + stride + cs, lane_ok, REG, a.seg_cap);
     while (base < n) {
-        load_cell(a, e_next, r, nxt);
+        load_cell<REG>(a, e_next, r, nxt);
         e_next = load_entry(list, n, base + 2 * stride + cs, lane_ok, REG, a.seg_cap);
         const bool act = cur.plane >= 0;
         // x pass: lane r < 9 owns source row y-4+r and forms the ten column sums
@@ -555,20 +563,28 @@ k_cell_filter(CellFilterArgs a) {
         // sums of outputs outside the map are zero, like the reference's zero border
         const int X = 8 * cur.x - 1 + r;
         const bool own = act && r >= 1 && r <= 8 && X < W;
+        unsigned hits = 0;
 #pragma unroll
         for (int j = 1; j <= 8; ++j) {
             const float c = S[j];
             const float left = __shfl_up(c, 1), right = __shfl_down(c, 1);
             const float ce = c + cur.e2;
-            const int Y = 8 * cur.y - 1 + j;
-            const bool ok = own && Y < H && c > cur.thr_lo && ce >= S[j - 1] && ce >= S[j + 1] && ce >= left && ce >= right;
-            if (ok) {
-                atomicAdd(a.cand_count + cur.plane, 1);
-                const int pos = atomicAdd(&sh.n_cand, 1);
-                if (pos < KF_LCAND)
-                    sh.cand[pos] = make_int2(cur.plane, (Y << 16) | X);
-                else
-                    atomicOr(a.cand_count + cur.plane, KF_OVERFLOW);  // no room: leave the plane to the exact kernel
+            const float m4 = fmaxf(fmaxf(S[j - 1], S[j + 1]), fmaxf(left, right));
+            hits |= (c > cur.thr_lo && ce >= m4) ? (1u << j) : 0u;
+        }
+        if (!own) hits = 0;
+        if (hits) {  // rare
+#pragma unroll
+            for (int j = 1; j <= 8; ++j) {
+                const int Y = 8 * cur.y - 1 + j;
+                if (((hits >> j) & 1u) && Y < H) {
+                    atomicAdd(a.cand_count + cur.plane, 1);
+                    const int pos = atomicAdd(&sh.n_cand, 1);
+                    if (pos < KF_LCAND)
+                        sh.cand[pos] = make_int2(cur.plane, (Y << 16) | X);
+                    else
+                        atomicOr(a.cand_count + cur.plane, KF_OVERFLOW);  // no room: leave the plane to the exact kernel
+                }
             }
         }
         cur = nxt;
