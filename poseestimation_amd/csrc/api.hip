@@ -82,7 +82,12 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     CRH(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     const size_t B = cfg->max_batch, PK = cfg->max_peaks_per_part;
     CR(dev_alloc(ctx, (void**)&ctx->raw, B * PD_N_PARTS * PK * sizeof(RawPeak)));
-    CR(dev_alloc(ctx, (void**)&ctx->raw_count, B * PD_N_PARTS * sizeof(int32_t)));
+    // counters that start every decode at zero share one allocation and one memset
+    ctx->zero_bytes = (2 * B * PD_N_PARTS + 96 + 3 * B) * sizeof(int32_t);
+    CR(dev_alloc(ctx, (void**)&ctx->zero_block, ctx->zero_bytes));
+    ctx->raw_count = ctx->zero_block;
+    ctx->cand_count = ctx->raw_count + B * PD_N_PARTS;                 // [B][18] + 3 x 32 list counters
+    ctx->absmax = (float*)(ctx->cand_count + B * PD_N_PARTS + 96);     // [B] max |v|, then [B] (thr_lo, e2)
     CR(dev_alloc(ctx, (void**)&ctx->pk_y, B * PD_N_PARTS * PK * sizeof(int32_t)));
     CR(dev_alloc(ctx, (void**)&ctx->pk_x, B * PD_N_PARTS * PK * sizeof(int32_t)));
     CR(dev_alloc(ctx, (void**)&ctx->pk_id, B * PD_N_PARTS * PK * sizeof(int32_t)));
@@ -126,11 +131,11 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void* ptrs[] = {ctx->stage_heat, ctx->stage_paf, ctx->full_heat, ctx->full_paf, ctx->tmp_up, ctx->tmp_in,
                     ctx->tmp_smooth, ctx->tmp_smooth2, ctx->tabs[0].i, ctx->tabs[0].f, ctx->tabs[1].i,
-                    ctx->tabs[1].f, ctx->tabs[2].i, ctx->tabs[2].f, ctx->raw, ctx->raw_count, ctx->pk_y,
+                    ctx->tabs[1].f, ctx->tabs[2].i, ctx->tabs[2].f, ctx->raw, ctx->zero_block, ctx->pk_y,
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->pack_off, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
-                    ctx->cand_count, ctx->absmax, ctx->heat_planar};
+                    ctx->heat_planar};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);

@@ -145,6 +145,8 @@ struct pd_ctx {
     size_t heat_planar_cap;
     int cand_cap;                    // CK
     // ---- peaks ----
+    int32_t* zero_block; // raw_count | cand_count + list counters | absmax + slack: cleared by one memset per decode
+    size_t zero_bytes;
     RawPeak* raw;        // [B][18][PK] unordered
     int32_t* raw_count;  // [B][18]
     int32_t *pk_y, *pk_x, *pk_id;  // [B][18][PK] sorted (y, x) ascending

@@ -750,14 +750,8 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     if (!ctx->cand || ctx->cand_cap != CK) {
         PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->cand) PD_HIP(ctx, hipFree(ctx->cand));
-        if (ctx->cand_count) PD_HIP(ctx, hipFree(ctx->cand_count));
-        if (ctx->absmax) PD_HIP(ctx, hipFree(ctx->absmax));
         ctx->cand = nullptr;
-        ctx->cand_count = nullptr;
-        ctx->absmax = nullptr;
         PD_HIP(ctx, hipMalloc(&ctx->cand, sizeof(int2) * planes_max * CK));
-        PD_HIP(ctx, hipMalloc(&ctx->cand_count, sizeof(int32_t) * (planes_max + 3 * KF_NSEG)));
-        PD_HIP(ctx, hipMalloc(&ctx->absmax, sizeof(float) * 3 * (size_t)ctx->cfg.max_batch));  // max |v| | (thr_lo, e2)
         ctx->cand_cap = CK;
     }
     rc = grow(ctx, (void**)&ctx->heat_planar, &ctx->heat_planar_cap, sizeof(float) * (size_t)B * PD_CH_HEAT * h * w);
@@ -809,8 +803,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     f.cand_n = counters;
     f.CK = CK;
 
-    PD_HIP(ctx, hipMemsetAsync(ctx->cand_count, 0, sizeof(int32_t) * (planes + 3 * KF_NSEG), ctx->stream));
-    PD_HIP(ctx, hipMemsetAsync(ctx->absmax, 0, sizeof(float) * B, ctx->stream));
+    // cand_count, the list counters and absmax were cleared together with raw_count
     pd_prof_begin(ctx, PD_STAGE_PLANAR);
     hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
                        h * w, ctx->heat_planar, (unsigned int*)ctx->absmax);

@@ -285,7 +285,7 @@ int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smo
 int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
     const int B = ctx->B, H = ctx->H, W = ctx->W;
     MapSource src = pd_heat_source(ctx);
-    PD_HIP(ctx, hipMemsetAsync(ctx->raw_count, 0, sizeof(int32_t) * B * PD_N_PARTS, ctx->stream));
+    PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));  // raw_count and the filter's counters
     const int f32mode = (ctx->src_kind == PD_SRC_FULLRES) ? ctx->heat_f32 : 0;
     // float32 data is thresholded in float32 (numpy compares a float32 array with a
     // Python float in float32)
