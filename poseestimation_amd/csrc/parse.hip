@@ -133,6 +133,7 @@ k_parse(ParseArgs a) {
 // one round trip to memory.  At most 64 open persons and WAVE_CONNS connections; an
 // image beyond that is handed to k_parse (person_count = -1).
 #define WAVE_CONNS 1024
+#define WAVE_IDS 2560  // peak ids the per-limb lookup tables cover
 
 __device__ __forceinline__ double bcast_d(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -145,8 +146,16 @@ k_parse_wave(ParseArgs a) {
     __shared__ int ids[PD_N_PARTS][64];
     __shared__ int c_ida[WAVE_CONNS], c_idb[WAVE_CONNS];
     __shared__ double c_score[WAVE_CONNS], c_ca[WAVE_CONNS], c_cb[WAVE_CONNS];
+    __shared__ short tab_a[WAVE_IDS], tab_b[WAVE_IDS];  // peak id -> connection of the current limb
+    __shared__ short own[64];                            // connection -> the person that matches it
+    __shared__ short newc[64];                           // new person slot -> its connection
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
+    for (int i = lane; i < WAVE_IDS; i += 64) {
+        tab_a[i] = -1;
+        tab_b[i] = -1;
+    }
+    own[lane] = -1;
     const int my_nc = lane < PD_N_LIMBS ? max(0, a.limb_count[b * PD_N_LIMBS + lane]) : 0;
     // exclusive prefix of the connection counts over the limbs
     int off = my_nc;
@@ -161,17 +170,45 @@ k_parse_wave(ParseArgs a) {
         if (lane == 0) a.person_count[b] = -1;
         return;
     }
+    // stage all connections: four per lane in flight, the limb of a flat index found
+    // from the prefix sums held across the lanes
+    for (int i0 = 0; i0 < total; i0 += 256) {
+        pd_conn r[4];
+        double cf0[4], cf1[4];
 #pragma unroll
-    for (int k = 0; k < PD_N_LIMBS; ++k) {
-        const int nc = __builtin_amdgcn_readlane(my_nc, k), o = __builtin_amdgcn_readlane(off, k);
-        for (int i = lane; i < nc; i += 64) {
-            const pd_conn r = a.conn[((size_t)b * PD_N_LIMBS + k) * a.PK + i];
-            const double* cf = a.conn_conf + (((size_t)b * PD_N_LIMBS + k) * a.PK + i) * 2;
-            c_ida[o + i] = r.id_a;
-            c_idb[o + i] = r.id_b;
-            c_score[o + i] = r.score;
-            c_ca[o + i] = cf[0];
-            c_cb[o + i] = cf[1];
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 64 + lane;
+            r[u].id_a = r[u].id_b = 0;
+            r[u].score = cf0[u] = cf1[u] = 0.0;
+            if (i < total) {
+                // limbs without connections share their offset with the next one: the scan
+                // lands on the last limb whose offset is <= i, which is the one that holds i
+                int k = 0, off_k = 0;
+#pragma unroll
+                for (int q = 1; q < PD_N_LIMBS; ++q) {
+                    const int oq = __builtin_amdgcn_readlane(off, q);
+                    if (oq <= i) {
+                        k = q;
+                        off_k = oq;
+                    }
+                }
+                const int local = i - off_k;
+                const size_t at = ((size_t)b * PD_N_LIMBS + k) * a.PK + local;
+                r[u] = a.conn[at];
+                cf0[u] = a.conn_conf[2 * at];
+                cf1[u] = a.conn_conf[2 * at + 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 64 + lane;
+            if (i < total) {
+                c_ida[i] = r[u].id_a;
+                c_idb[i] = r[u].id_b;
+                c_score[i] = r[u].score;
+                c_ca[i] = cf0[u];
+                c_cb[i] = cf1[u];
+            }
         }
     }
 #pragma unroll
@@ -188,6 +225,76 @@ k_parse_wave(ParseArgs a) {
         // the two id columns this limb tests stay in registers for the whole limb; LDS
         // is written through and only re-read around the (rare) merges
         int col_a = ids[pa][lane], col_b = ids[pb][lane];
+        // Whole limb at once.  When every connection of the limb has its own two peaks
+        // (always so for connections that come from the matching stage), every person
+        // matches at most one connection and every connection at most one person, the
+        // sequential loop below would touch disjoint persons: each matched person takes
+        // its connection's end, each unmatched connection opens a person, in connection
+        // order.  Anything else (shared peaks, two owners, merges) takes the loop.
+        if (nc <= 64) {
+            const bool is_c = lane < nc;
+            const int ida = is_c ? c_ida[o + lane] : 0, idb = is_c ? c_idb[o + lane] : 0;
+            const bool in_range = !is_c || (ida >= 0 && ida < WAVE_IDS && idb >= 0 && idb < WAVE_IDS);
+            bool fast = __ballot(!in_range) == 0ull;
+            if (fast) {
+                if (is_c) {
+                    tab_a[ida] = (short)lane;
+                    tab_b[idb] = (short)lane;
+                }
+                __syncthreads();
+                const bool dup = is_c && (tab_a[ida] != lane || tab_b[idb] != lane);
+                const bool is_p = lane < n;
+                const int ca = (is_p && col_a >= 0 && col_a < WAVE_IDS) ? tab_a[col_a] : -1;
+                const int cb = (is_p && col_b >= 0 && col_b < WAVE_IDS) ? tab_b[col_b] : -1;
+                const bool two = ca >= 0 && cb >= 0 && ca != cb;
+                const int mc = ca >= 0 ? ca : cb;
+                if (mc >= 0) own[mc] = (short)lane;
+                __syncthreads();
+                const bool shared_conn = mc >= 0 && own[mc] != lane;
+                fast = __ballot(dup || two || shared_conn) == 0ull;
+                const bool unmatched = is_c && own[lane] < 0;
+                const unsigned long long um = __ballot(unmatched);
+                const int n_new = (a.mode == PD_MODE_D || k < 17) ? __builtin_popcountll(um) : 0;
+                const bool room = n + n_new <= 64 && n + n_new <= a.max_persons;
+                if (fast && room) {
+                    if (mc >= 0) {
+                        const int tb = c_idb[o + mc];
+                        if (col_b != tb) {  // :210 / predict.py:205
+                            col_b = tb;
+                            ids[pb][lane] = tb;
+                            my_cnt += 1;
+                            my_score += c_cb[o + mc] + c_score[o + mc];
+                        }
+                    }
+                    if (n_new > 0) {
+                        if (unmatched) newc[__builtin_popcountll(um & ((1ull << lane) - 1ull))] = (short)lane;
+                        __syncthreads();
+                        if (lane >= n && lane < n + n_new) {  // utils/postprocess.py:196-205 / predict.py:228-244
+                            const int c = newc[lane - n];
+                            col_a = c_ida[o + c];
+                            col_b = c_idb[o + c];
+                            ids[pa][lane] = col_a;
+                            ids[pb][lane] = col_b;
+                            my_score = (c_ca[o + c] + c_cb[o + c]) + c_score[o + c];
+                            my_cnt = 2;
+                        }
+                        n += n_new;
+                    }
+                }
+                // leave the tables clean for the next limb
+                if (is_c) {
+                    tab_a[ida] = -1;
+                    tab_b[idb] = -1;
+                }
+                own[lane] = -1;
+                __syncthreads();
+                if (fast && room) continue;
+                if (fast && !room) {  // more than 64 open persons: the table kernel takes the image
+                    rc = 1;
+                    break;
+                }
+            }
+        }
         for (int c0 = 0; c0 < nc && rc == 0; c0 += 64) {
             // this chunk's connections, one per lane, broadcast below with readlane
             const int mine = min(o + c0 + lane, WAVE_CONNS - 1);
