@@ -21,12 +21,8 @@ struct ParseArgs {
     int only_flagged;  // != 0: only images the fast kernel handed over (count -1)
 };
 
-__global__ void __launch_bounds__(64)
-k_parse(ParseArgs a) {
-    extern __shared__ __align__(16) double tab[];  // [max_persons][20]
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    if (a.only_flagged && a.person_count[b] != -1) return;
+// The table form for image b; tab holds max_persons rows of 20 doubles in LDS.
+__device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
     int n = 0;           // live rows
     int err = PD_OK;
     // the limb's connection counts, one per lane, fetched once
@@ -125,6 +121,14 @@ k_parse(ParseArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(64)
+k_parse(ParseArgs a) {
+    extern __shared__ __align__(16) double tab[];  // [max_persons][20]
+    const int b = blockIdx.x;
+    if (a.only_flagged && a.person_count[b] != -1) return;
+    parse_table(a, b, threadIdx.x, tab);
+}
+
 // ---- one lane per person -----------------------------------------------------------
 // Lane j owns person j: its score and part count live in that lane's registers and its
 // 18 part ids in LDS as ids[part][j] (int32, exact: ids are small integers and a merge
@@ -144,8 +148,12 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
 __global__ void __launch_bounds__(64)
 k_parse_wave(ParseArgs a) {
     __shared__ int ids[PD_N_PARTS][64];
-    __shared__ int c_ida[WAVE_CONNS], c_idb[WAVE_CONNS];
-    __shared__ double c_score[WAVE_CONNS], c_ca[WAVE_CONNS], c_cb[WAVE_CONNS];
+    __shared__ __align__(16) double c_all[WAVE_CONNS * 4];  // staged connections; the table form's rows on hand-over
+    double* c_score = c_all;
+    double* c_ca = c_all + WAVE_CONNS;
+    double* c_cb = c_all + 2 * WAVE_CONNS;
+    int* c_ida = (int*)(c_all + 3 * WAVE_CONNS);
+    int* c_idb = c_ida + WAVE_CONNS;
     __shared__ short tab_a[WAVE_IDS], tab_b[WAVE_IDS];  // peak id -> connection of the current limb
     __shared__ short own[64];                            // connection -> the person that matches it
     __shared__ short newc[64];                           // new person slot -> its connection
@@ -167,7 +175,11 @@ k_parse_wave(ParseArgs a) {
     const int total = __builtin_amdgcn_readlane(off, PD_N_LIMBS - 1);
     off -= my_nc;
     if (total > WAVE_CONNS) {
-        if (lane == 0) a.person_count[b] = -1;
+        if (a.only_flagged) {  // the table kernel follows
+            if (lane == 0) a.person_count[b] = -1;
+        } else {
+            parse_table(a, b, lane, c_all);
+        }
         return;
     }
     // stage all connections: four per lane in flight, the limb of a flat index found
@@ -377,8 +389,13 @@ k_parse_wave(ParseArgs a) {
         }
         __syncthreads();  // this limb's writes are visible before the next limb loads its columns
     }
-    if (rc == 1) {
-        if (lane == 0) a.person_count[b] = -1;  // k_parse redoes this image
+    if (rc == 1) {  // more than 64 open persons: the table form redoes this image
+        if (a.only_flagged) {
+            if (lane == 0) a.person_count[b] = -1;
+        } else {
+            __syncthreads();
+            parse_table(a, b, lane, c_all);
+        }
         return;
     }
     if (rc == 2) {
@@ -535,10 +552,11 @@ int pd_launch_parse(pd_ctx* ctx) {
         a.only_flagged = 0;
         hipLaunchKernelGGL(k_parse, dim3(ctx->B), dim3(64), lds, ctx->stream, a);
     } else {
-        // one lane per person; images with more than 64 open persons fall through to the table kernel
-        a.only_flagged = 1;
+        // one lane per person; images with more than 64 open persons take the table form, inside
+        // the same kernel when its rows fit the staging area, else in a kernel of its own
+        a.only_flagged = (size_t)a.max_persons * 20 > (size_t)WAVE_CONNS * 4;
         hipLaunchKernelGGL(k_parse_wave, dim3(ctx->B), dim3(64), 0, ctx->stream, a);
-        hipLaunchKernelGGL(k_parse, dim3(ctx->B), dim3(64), lds, ctx->stream, a);
+        if (a.only_flagged) hipLaunchKernelGGL(k_parse, dim3(ctx->B), dim3(64), lds, ctx->stream, a);
     }
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
