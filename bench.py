@@ -55,8 +55,14 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
+    # PD_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL gather of the skeleton buffers)
+    # with a single rank, which is how that path is rehearsed on a one-GPU box
+    use_dist = world > 1 or os.environ.get('PD_BENCH_FORCE_DIST') == '1'
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    elif use_dist:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1,
+                                device_id=torch.device('cuda', local_rank))
 
     B, H, W, people, desc = WORKLOADS[args.workload]
     if args.people:      # experiments only: a fixed number of people per image
@@ -75,32 +81,62 @@ def main():
                          max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000)
             for _ in range(args.contexts)]
     eng = engs[0]
-    gather_cap = 1 << 20
-    while gather_cap < B * 16384:
+    gather_cap = 1 << 18      # per rank and step: header, count tables, peaks, person rows
+    while gather_cap < B * 4096:
         gather_cap <<= 1
 
-    def finish(e):
-        res = e.ctx.fetch()              # waits for that stream; packed skeletons now on the host
-        if world > 1:
-            return sharding.gather_results(res, gather_cap)
-        return res
+    gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap) if use_dist else None
 
     def run(nsteps):
-        """nsteps steps = nsteps batches decoded, fetched and (N > 1) gathered."""
-        pending, last = [], None
+        """nsteps steps = nsteps batches decoded and their skeletons brought to the host
+        (N = 1: the packed results of the batch; N > 1: every rank's peaks and person
+        rows gathered to rank 0 over RCCL)."""
+        n, last = len(engs), None
+        if gather is None:
+            pending = []
+            for i in range(nsteps):
+                e = engs[i % n]
+                if len(pending) == n:
+                    last = pending.pop(0).ctx.fetch()   # waits for that stream; results now on the host
+                e.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
+                pending.append(e)
+            while pending:
+                last = pending.pop(0).ctx.fetch()
+            return last
+        # a context is free again once its decode has been waited for and the gather of its
+        # skeleton buffer has finished; n - 1 decodes and one gather are in flight
+        free, decoding, gathering = list(range(n)), [], []
+
+        def to_gather():
+            s = decoding.pop(0)
+            engs[s].ctx.sync()
+            gather.start(s)
+            gathering.append(s)
+
+        def retire():
+            s = gathering.pop(0)
+            free.append(s)
+            return gather.finish(s)
+
         for i in range(nsteps):
-            e = engs[i % len(engs)]
-            if len(pending) == len(engs):
-                last = finish(pending.pop(0))
-            e.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
-            pending.append(e)
-        while pending:
-            last = finish(pending.pop(0))
+            if not free:
+                if not gathering:
+                    to_gather()
+                last = retire()
+            s = free.pop(0)
+            engs[s].enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
+            decoding.append(s)
+            while len(decoding) > max(1, n - 1):
+                to_gather()
+        while decoding:
+            to_gather()
+        while gathering:
+            last = retire()
         return last
 
     def barrier():
         torch.cuda.synchronize()         # device-wide: covers the contexts' own streams
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +174,7 @@ def main():
             a = prof.get(k, (0.0, 0))
             prof[k] = (a[0] + v[0], a[1] + v[1])
         e.ctx.profile(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -179,7 +215,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': desc, 'batch_per_gpu': B, 'mode': args.mode,
                        'people_per_image': list(people) if isinstance(people, tuple) else people,
-                       'outputs': 'packed skeleton lists copied to the host every step'},
+                       'outputs': 'packed skeleton lists copied to the host every step' if gather is None else
+                                  'peaks and person rows of every rank gathered to rank 0 (RCCL) and copied to its host every step'},
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': sm_n,
@@ -187,11 +224,11 @@ def main():
             'job_hbm_frac_per_gpu': (value / world) * job_bytes / 1e9 / HBM_PEAK_GBS,
             'stage_ms_per_launch_untimed_pass': {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
-        res0 = last
+        res0 = last if gather is None else sharding.SkeletonGather.results(last)
         out['persons_last_step'] = int(res0['person_count'].sum())
         out['filter_stats_last_step'] = eng.ctx.filter_stats()
 
-        if world == 1 and not args.no_cpu:
+        if gather is None and not args.no_cpu:
             from oracle import decode_ref as ref
             ncpu = min(args.cpu_images, B)
             r = Results(res0, eng.mode)
@@ -215,7 +252,7 @@ def main():
             out['parity_ok'] = bool(ok)
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -202,6 +202,16 @@ int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);
  * sigma = 3), (B, 18, H, W) float64; test hook for the filter alone. */
 int pd_debug_smoothed(pd_ctx* ctx, double* out);
 
+/* A caller-owned device buffer that receives, with every pd_pack (so with every decode),
+ * a second copy of the packed results without the connection lists: the layout of the
+ * result buffer with n_conns = 0 and a zero limb table -- what a multi-GPU job gathers
+ * (peaks and person rows are all evaluate.py:44-74 reads).  header[5] != 0 means the
+ * buffer was too small for the payload (header[5] = bytes needed); the header and the
+ * count tables are always written.  NULL removes the buffer.  The buffer belongs to the
+ * context's stream until the results have been waited for.  No counterpart in the
+ * reference: the reference is single-process. */
+int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t capacity);
+
 /* Counters of the last peak stage that went through the candidate filter
  * (PD_IMPL_FAST on network-resolution sources): out[0] candidates handed to the exact
  * verification, out[1] / out[2] active 8 x 8 pixel cells with interior / border

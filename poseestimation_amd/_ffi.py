@@ -21,7 +21,7 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer']
 
 STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells', 'filter_border']
 
@@ -123,6 +123,7 @@ def lib():
     L.pd_profile.argtypes = [vp, i32]
     L.pd_profile_stages.argtypes = [vp, C.c_uint32]
     L.pd_filter_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.pd_set_skeleton_buffer.argtypes = [vp, vp, C.c_uint64]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -310,6 +311,14 @@ class Context:
         ptrs = [C.c_void_p() for _ in range(6)]
         self.check(self.L.pd_packed_device(self._h, *[C.byref(p) for p in ptrs]))
         return [p.value for p in ptrs]
+
+    def set_skeleton_buffer(self, device_ptr, capacity):
+        """Device buffer that receives peaks + person rows (no connections) with every pack."""
+        self.check(self.L.pd_set_skeleton_buffer(self._h, device_ptr, capacity))
+
+    def sync(self):
+        """Wait for everything queued on the context's stream; raises on a decode error."""
+        self.check(self.L.pd_sync_totals(self._h, None))
 
     def filter_stats(self):
         """Counters of the last filtered peak stage: candidates, interior cells, border

@@ -411,6 +411,20 @@ extern "C" int pd_debug_smoothed(pd_ctx* ctx, double* out) {
     return rc;
 }
 
+extern "C" int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t capacity) {
+    PD_CHECK_CTX(ctx);
+    if (device_ptr) {
+        if ((uintptr_t)device_ptr & 15) PD_FAIL(ctx, PD_E_INVALID, "pd_set_skeleton_buffer: the buffer must be 16-byte aligned");
+        const size_t least = pd_res_layout(ctx->cfg.max_batch).off_payload;
+        if (capacity < least)
+            PD_FAIL(ctx, PD_E_INVALID, "pd_set_skeleton_buffer: %llu bytes cannot hold the count tables of %d images (%zu bytes)",
+                    (unsigned long long)capacity, ctx->cfg.max_batch, least);
+    }
+    ctx->skel_dst = (unsigned char*)device_ptr;
+    ctx->skel_cap = device_ptr ? (size_t)capacity : 0;
+    return PD_OK;
+}
+
 extern "C" int pd_filter_stats(pd_ctx* ctx, int64_t* out) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
@@ -635,6 +649,7 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     key.mode = ctx->mode;
     key.impl = ctx->impl;
     key.prof = ctx->prof_on;
+    key.skel = ctx->skel_dst;
     if (ctx->graph_exec && memcmp(&key, &ctx->graph_key, sizeof(key)) == 0) {
         PD_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
         ctx->have_peaks = ctx->have_conns = ctx->have_persons = ctx->packed = 1;

@@ -88,6 +88,7 @@ struct GraphKey {
     double t1, t2;
     int mode, impl;
     uint32_t prof;
+    const void* skel;
 };
 
 struct TableSlot {
@@ -172,6 +173,8 @@ struct pd_ctx {
     unsigned char* res_host;
     size_t res_cap, res_spec, res_have;
     int have_peaks, have_conns, have_persons, packed;
+    unsigned char* skel_dst;  // caller's device buffer for the skeleton copy of the results (or NULL)
+    size_t skel_cap;
     // ---- stage timing (pd_profile) ----
     uint32_t prof_on;               // bit s set: stage s is timed
     int prof_open;                  // a start event is waiting for its stop

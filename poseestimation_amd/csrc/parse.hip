@@ -429,6 +429,7 @@ struct PackArgs {
     const pd_conn* conn;
     const double* persons;
     unsigned char* res;  // result buffer: header | count tables | peaks | conns | persons
+    unsigned long long cap;  // bytes behind res, 0 = large enough by construction
     ResLayout lay;
 };
 
@@ -484,6 +485,9 @@ k_pack(PackArgs a) {
         s_lbase[PD_N_LIMBS] = run;
     }
     __syncthreads();
+    const unsigned long long need = a.lay.off_payload + (unsigned long long)s_tot[3] * sizeof(pd_peak) +
+                                    (unsigned long long)s_tot[4] * sizeof(pd_conn) + (unsigned long long)s_tot[5] * 20 * sizeof(double);
+    const bool fits = a.cap == 0 || need <= a.cap;
     if (b == 0 && tid == 0) {
         int64_t* head = (int64_t*)a.res;
         const int fb = min(min(s_redbad[0], s_redbad[1]), min(s_redbad[2], s_redbad[3]));
@@ -492,6 +496,7 @@ k_pack(PackArgs a) {
         head[2] = s_tot[4];
         head[3] = s_tot[5];
         head[4] = fb == 0x7fffffff ? -1 : fb;
+        head[5] = fits ? 0 : (int64_t)need;  // != 0: the buffer is too small, no payload was written
     }
     // count tables of this image
     if (tid < PD_N_PARTS)
@@ -507,7 +512,7 @@ k_pack(PackArgs a) {
     pd_conn* out_conns = (pd_conn*)(a.res + a.lay.off_payload + n_peaks * sizeof(pd_peak)) + s_tot[1];
     double* out_persons = (double*)(a.res + a.lay.off_payload + n_peaks * sizeof(pd_peak) + n_conns * sizeof(pd_conn)) +
                           s_tot[2] * 20;
-    if (a.have_peaks) {
+    if (a.have_peaks && fits) {
         const int n = s_pbase[PD_N_PARTS];
         for (int i = tid; i < n; i += 256) {
             int p = 0;
@@ -520,7 +525,7 @@ k_pack(PackArgs a) {
             out_peaks[i] = q;
         }
     }
-    if (a.have_conns) {
+    if (a.have_conns && fits) {
         const int n = s_lbase[PD_N_LIMBS];
         for (int i = tid; i < n; i += 256) {
             int k = 0;
@@ -528,7 +533,7 @@ k_pack(PackArgs a) {
             out_conns[i] = a.conn[((size_t)b * PD_N_LIMBS + k) * a.PK + (i - s_lbase[k])];
         }
     }
-    if (a.have_persons) {
+    if (a.have_persons && fits) {
         const int n = a.person_count[b] * 20;
         const double* src = a.persons + (size_t)b * a.max_persons * 20;
         for (int i = tid; i < n; i += 256) out_persons[i] = src[i];
@@ -582,9 +587,17 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.conn = ctx->conn;
     a.persons = ctx->persons;
     a.res = ctx->res_dev;
+    a.cap = 0;
     a.lay = pd_res_layout(ctx->B);
     pd_prof_begin(ctx, PD_STAGE_PACK);
     hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
+    if (ctx->skel_dst) {
+        // the caller's device buffer gets the same layout without the connection lists
+        a.res = ctx->skel_dst;
+        a.cap = ctx->skel_cap;
+        a.have_conns = 0;
+        hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
+    }
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;

@@ -96,3 +96,81 @@ def gather_results(res, capacity, group=None, dst=0):
     if blobs is None:
         return None
     return concat_results([unpack_blob(b) for b in blobs])
+
+
+class SkeletonGather:
+    """The per-step exchange of a sharded decode: every rank's peaks and person rows
+    (the library's skeleton buffer, see ``Context.set_skeleton_buffer``) are gathered to
+    rank ``dst`` with one fixed-size ``dist.gather`` per step, straight from the device
+    buffer the pack kernel wrote (backend "nccl" = RCCL; with "gloo" the buffer is
+    staged through host memory, which is what the CPU tests run).
+
+    One slot per decode context.  ``start(slot)`` launches the gather of that context's
+    buffer (its stream must have been waited for), ``finish(slot)`` waits for it and
+    returns, on ``dst``, a ``(world, capacity)`` uint8 array of the ranks' blobs in rank
+    order = image order; the slot's buffer may be overwritten by the next decode only
+    after ``finish``.
+    """
+
+    def __init__(self, contexts, capacity, group=None, dst=0, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group, self.dst, self.capacity = group, dst, int(capacity)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.on_gpu = dist.get_backend(group) == 'nccl'
+        dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        n = len(contexts)
+        self.send = [torch.zeros(self.capacity, dtype=torch.uint8, device=dev) for _ in range(n)]
+        for ctx, t in zip(contexts, self.send):
+            ctx.set_skeleton_buffer(t.data_ptr(), self.capacity)
+        self.stage = None if self.on_gpu else [torch.zeros(self.capacity, dtype=torch.uint8) for _ in range(n)]
+        self.recv = self.host = None
+        if self.rank == dst:
+            rdev = dev if self.on_gpu else torch.device('cpu')
+            self.recv = [torch.zeros(self.world * self.capacity, dtype=torch.uint8, device=rdev) for _ in range(n)]
+            if self.on_gpu:
+                self.host = [torch.zeros(self.world * self.capacity, dtype=torch.uint8).pin_memory() for _ in range(n)]
+        self.work = [None] * n
+
+    def start(self, slot):
+        src = self.send[slot]
+        if not self.on_gpu:
+            self.stage[slot].copy_(src)
+            src = self.stage[slot]
+        gl = None
+        if self.rank == self.dst:
+            gl = list(self.recv[slot].view(self.world, self.capacity).unbind(0))
+        self.work[slot] = self.dist.gather(src, gather_list=gl, dst=self.dst, group=self.group, async_op=True)
+
+    def finish(self, slot):
+        work, self.work[slot] = self.work[slot], None
+        if work is None:
+            return None
+        work.wait()
+        out = None
+        if self.on_gpu:
+            if self.rank == self.dst:
+                self.host[slot].copy_(self.recv[slot], non_blocking=True)
+            # wait() only orders the current stream behind the collective: the host has to
+            # wait too before the send buffer is handed back to the decode stream
+            self.torch.cuda.current_stream().synchronize()
+            if self.rank == self.dst:
+                out = self.host[slot].numpy()
+        elif self.rank == self.dst:
+            out = self.recv[slot].numpy()
+        return None if out is None else out.reshape(self.world, self.capacity)
+
+    @staticmethod
+    def results(rows):
+        """Blobs of all ranks -> one result dict in image order (connections are not part
+        of the exchange: ``conns`` is empty and ``limb_count`` zero)."""
+        parts = []
+        for r, row in enumerate(rows):
+            need = int(np.ascontiguousarray(row[:64]).view(np.int64)[5])
+            if need:
+                raise ValueError('rank %d: its skeleton blob needs %d bytes, the gather capacity is %d'
+                                 % (r, need, row.size))
+            parts.append(unpack_blob(row))
+        return concat_results(parts)

@@ -307,3 +307,34 @@ def test_multiscale_average_and_decode(pdec):
     np.testing.assert_array_equal(res.candidate(0), cand)
     gio.assert_persons_equal(res.subset(0), subset, RTOL)
     eng.close()
+
+
+def test_skeleton_buffer_holds_peaks_and_persons(pdec):
+    """The device buffer a multi-GPU job gathers: the packed results without the
+    connection lists, written by the pack stage; too small a buffer is reported in
+    the header, never overrun."""
+    import torch
+    from poseestimation_amd import _ffi, sharding, synth
+    H = W = 184
+    heat, paf = synth.batch(4, H, W, (1, 4), seed0=70, paf_order='xy')
+    eng = pdec.DecodeEngine(max_batch=4, max_h=H, max_w=W, mode='D')
+    buf = torch.full((1 << 16,), 255, dtype=torch.uint8, device='cuda')
+    eng.ctx.set_skeleton_buffer(buf.data_ptr(), buf.numel())
+    res = eng.decode_batch(heat, paf).packed
+    got = sharding.SkeletonGather.results(buf.cpu().numpy()[None])
+    for key in ('part_count', 'person_count', 'status', 'peaks', 'persons'):
+        assert np.array_equal(got[key], res[key]), key
+    assert len(got['conns']) == 0 and not got['limb_count'].any() and len(res['conns']) > 0
+    # a buffer that only holds the tables: header[5] = bytes needed, payload untouched
+    small = int(_ffi.res_layout(4)[4]) + 64
+    buf.fill_(255)
+    eng.ctx.set_skeleton_buffer(buf.data_ptr(), small)
+    eng.decode_batch(heat, paf)
+    raw = buf.cpu().numpy()
+    need = int(raw[:64].view(np.int64)[5])
+    assert need == _ffi.res_layout(4)[4] + len(res['peaks']) * 16 + len(res['persons']) * 160
+    assert np.all(raw[small:] == 255)
+    with pytest.raises(ValueError):
+        sharding.SkeletonGather.results(raw[None])
+    eng.ctx.set_skeleton_buffer(None, 0)
+    eng.close()

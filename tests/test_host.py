@@ -140,6 +140,51 @@ if rank == 0:
     print('GATHER_OK')
 else:
     assert out is None
+
+# the per-step exchange of the bench: skeleton buffers (no connection lists), two slots in flight
+import torch
+class FakeCtx:
+    def set_skeleton_buffer(self, ptr, cap):
+        self.ptr, self.cap = ptr, cap
+ctxs = [FakeCtx(), FakeCtx()]
+cap = 1 << 15
+g = sharding.SkeletonGather(ctxs, cap, device=torch.device('cpu'))
+assert all(c.cap == cap and c.ptr == t.data_ptr() for c, t in zip(ctxs, g.send))
+def skeleton(seed):
+    r = _fake_results(hi - lo, seed)
+    r['conns'] = r['conns'][:0]
+    r['limb_count'] = np.zeros_like(r['limb_count'])
+    return r
+for slot in (0, 1):
+    blob = sharding.pack_blob(skeleton(70 + 10 * slot + rank))
+    g.send[slot][:blob.size] = torch.from_numpy(blob)
+    g.start(slot)
+for slot in (0, 1):
+    rows = g.finish(slot)
+    if rank == 0:
+        got = sharding.SkeletonGather.results(rows)
+        sizes = [sharding.shard_range(9, 2, r) for r in range(2)]
+        want = []
+        for r, (a, b) in enumerate(sizes):
+            w = _fake_results(b - a, 70 + 10 * slot + r)
+            w['conns'] = w['conns'][:0]
+            w['limb_count'] = np.zeros_like(w['limb_count'])
+            want.append(w)
+        want = sharding.concat_results(want)
+        assert got['B'] == 9 and len(got['conns']) == 0
+        for k in ('part_count', 'person_count', 'peaks', 'persons'):
+            assert np.array_equal(got[k], want[k]), k
+    else:
+        assert rows is None
+if rank == 0:
+    bad = g.recv[0].numpy().reshape(2, cap).copy()
+    bad[1, :64].view(np.int64)[5] = 123456
+    try:
+        sharding.SkeletonGather.results(bad)
+        raise SystemExit('a truncated blob was accepted')
+    except ValueError:
+        pass
+    print('SKELETON_GATHER_OK')
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -156,7 +201,7 @@ def test_gather_world_size_2_gloo(tmp_path):
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert 'GATHER_OK' in outs[0]
+    assert 'GATHER_OK' in outs[0] and 'SKELETON_GATHER_OK' in outs[0]
 
 
 def test_synth_is_deterministic_and_shaped():
