@@ -58,6 +58,12 @@ def main():
     # PD_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL gather of the skeleton buffers)
     # with a single rank, which is how that path is rehearsed on a one-GPU box
     use_dist = world > 1 or os.environ.get('PD_BENCH_FORCE_DIST') == '1'
+    if use_dist:
+        # With a process group alive, replaying the captured launch graph ended in a GPU
+        # memory fault on this stack (ROCm 7.2 / torch 2.10, first or second replay, while
+        # the process group's watchdog thread polls its events); eager launches do not.
+        # The contexts are created without graph replay: about 15 % slower per GPU.
+        os.environ['PD_NO_GRAPH'] = '1'
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     elif use_dist:

@@ -325,21 +325,24 @@ k_match(MatchArgs a) {
             const int idx = have ? s_idx[i] : 0;
             const double sc = have ? s_score[i] : 0.0;
             const int ia = idx / nB, ib = idx - ia * nB;
+            // every lane fetches what a pick of its candidate would store, so that the
+            // pick loop itself waits for no memory
+            pd_conn r;
+            r.id_a = have ? idA[ia] : 0;
+            r.id_b = have ? idB[ib] : 0;
+            r.ia = ia;
+            r.ib = ib;
+            r.score = sc;
+            const double conf_a = have ? scA[ia] : 0.0, conf_b = have ? scB[ib] : 0.0;
             while (count < limit) {
                 const bool ok = have && !usedA[ia] && !usedB[ib];
                 const unsigned long long m = __ballot(ok);
                 if (m == 0ull) break;
                 const int first = __builtin_ctzll(m);
                 if (lane == first) {
-                    pd_conn r;
-                    r.id_a = idA[ia];
-                    r.id_b = idB[ib];
-                    r.ia = ia;
-                    r.ib = ib;
-                    r.score = sc;
                     rows[count] = r;
-                    conf[2 * count] = scA[ia];
-                    conf[2 * count + 1] = scB[ib];
+                    conf[2 * count] = conf_a;
+                    conf[2 * count + 1] = conf_b;
                     usedA[ia] = 1;
                     usedB[ib] = 1;
                     have = false;
