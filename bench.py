@@ -91,7 +91,8 @@ def main():
     while gather_cap < B * 4096:
         gather_cap <<= 1
 
-    gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap) if use_dist else None
+    GATHER_DEPTH = 2   # decodes per context between two gathers
+    gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap, depth=GATHER_DEPTH) if use_dist else None
 
     def run(nsteps):
         """nsteps steps = nsteps batches decoded and their skeletons brought to the host
@@ -109,35 +110,27 @@ def main():
             while pending:
                 last = pending.pop(0).ctx.fetch()
             return last
-        # a context is free again once its decode has been waited for and the gather of its
-        # skeleton buffer has finished; n - 1 decodes and one gather are in flight
-        free, decoding, gathering = list(range(n)), [], []
-
-        def to_gather():
-            s = decoding.pop(0)
-            engs[s].ctx.sync()
+        # rounds of GATHER_DEPTH decodes per context; the gather of round r (set r % 2 of the
+        # send buffers) is in flight while round r + 1 decodes; the host never waits for a decode
+        last, r, done = None, 0, 0
+        pending = [False, False]
+        while done < nsteps:
+            s = r % 2
+            if pending[s]:
+                rows = gather.finish(s)
+                last = rows if rows is not None else last
+            k = min(n * GATHER_DEPTH, nsteps - done)
+            for j in range(k):
+                gather.point(s, j, j % n)
+                engs[j % n].enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
             gather.start(s)
-            gathering.append(s)
-
-        def retire():
-            s = gathering.pop(0)
-            free.append(s)
-            return gather.finish(s)
-
-        for i in range(nsteps):
-            if not free:
-                if not gathering:
-                    to_gather()
-                last = retire()
-            s = free.pop(0)
-            engs[s].enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
-            decoding.append(s)
-            while len(decoding) > max(1, n - 1):
-                to_gather()
-        while decoding:
-            to_gather()
-        while gathering:
-            last = retire()
+            pending[s] = True
+            done += k
+            r += 1
+        for s in (r % 2, (r + 1) % 2):
+            if pending[s]:
+                rows = gather.finish(s)
+                last = rows if rows is not None else last
         return last
 
     def barrier():
@@ -230,7 +223,7 @@ def main():
             'job_hbm_frac_per_gpu': (value / world) * job_bytes / 1e9 / HBM_PEAK_GBS,
             'stage_ms_per_launch_untimed_pass': {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
-        res0 = last if gather is None else sharding.SkeletonGather.results(last)
+        res0 = last if gather is None else sharding.SkeletonGather.results(last)[0]
         out['persons_last_step'] = int(res0['person_count'].sum())
         out['filter_stats_last_step'] = eng.ctx.filter_stats()
 

@@ -99,78 +99,102 @@ def gather_results(res, capacity, group=None, dst=0):
 
 
 class SkeletonGather:
-    """The per-step exchange of a sharded decode: every rank's peaks and person rows
-    (the library's skeleton buffer, see ``Context.set_skeleton_buffer``) are gathered to
-    rank ``dst`` with one fixed-size ``dist.gather`` per step, straight from the device
-    buffer the pack kernel wrote (backend "nccl" = RCCL; with "gloo" the buffer is
-    staged through host memory, which is what the CPU tests run).
+    """The exchange of a sharded decode: every rank's peaks and person rows (the
+    library's skeleton buffer, see ``Context.set_skeleton_buffer``) are gathered to rank
+    ``dst`` with one fixed-size ``dist.gather`` per *round* -- ``depth`` decodes on each
+    of the rank's contexts -- straight from the device buffers the pack kernels wrote
+    (backend "nccl" = RCCL; with "gloo" the buffers are staged through host memory, which
+    is what the CPU tests run).
 
-    One slot per decode context.  ``start(slot)`` launches the gather of that context's
-    buffer (its stream must have been waited for), ``finish(slot)`` waits for it and
-    returns, on ``dst``, a ``(world, capacity)`` uint8 array of the ranks' blobs in rank
-    order = image order; the slot's buffer may be overwritten by the next decode only
-    after ``finish``.
+    There are ``sets`` send buffers (two: the decodes of round r + 1 run while the gather
+    of round r is in flight), each with ``contexts * depth`` slices of ``capacity`` bytes.
+    Per round: ``point(s, j, i)`` directs the next decode of context ``i`` to slice ``j``
+    of set ``s`` and the caller enqueues that decode; ``start(s)`` launches the gather
+    behind the round's decodes (on the GPU the collective waits for the contexts' streams
+    itself, the host does not block); ``finish(s)`` -- at the latest before set ``s`` is
+    used again -- waits for it and returns, on ``dst``, a ``(world, slices, capacity)``
+    uint8 array: rank-major, then in slice order.
     """
 
-    def __init__(self, contexts, capacity, group=None, dst=0, device=None):
+    def __init__(self, contexts, capacity, group=None, dst=0, device=None, sets=2, depth=1):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.group, self.dst, self.capacity = group, dst, int(capacity)
+        self.contexts = list(contexts)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.on_gpu = dist.get_backend(group) == 'nccl'
         dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
-        n = len(contexts)
-        self.send = [torch.zeros(self.capacity, dtype=torch.uint8, device=dev) for _ in range(n)]
-        for ctx, t in zip(contexts, self.send):
-            ctx.set_skeleton_buffer(t.data_ptr(), self.capacity)
-        self.stage = None if self.on_gpu else [torch.zeros(self.capacity, dtype=torch.uint8) for _ in range(n)]
+        n = self.n = len(self.contexts) * int(depth)   # slices per set
+        row = n * self.capacity
+        self.send = [torch.zeros(row, dtype=torch.uint8, device=dev) for _ in range(sets)]
+        self.stage = None if self.on_gpu else [torch.zeros(row, dtype=torch.uint8) for _ in range(sets)]
         self.recv = self.host = None
         if self.rank == dst:
             rdev = dev if self.on_gpu else torch.device('cpu')
-            self.recv = [torch.zeros(self.world * self.capacity, dtype=torch.uint8, device=rdev) for _ in range(n)]
+            self.recv = [torch.zeros(self.world * row, dtype=torch.uint8, device=rdev) for _ in range(sets)]
             if self.on_gpu:
-                self.host = [torch.zeros(self.world * self.capacity, dtype=torch.uint8).pin_memory() for _ in range(n)]
-        self.work = [None] * n
+                self.host = [torch.zeros(self.world * row, dtype=torch.uint8).pin_memory() for _ in range(sets)]
+        self.work = [None] * sets
+        self.streams = self.copy_stream = None
+        if self.on_gpu:
+            # the contexts' own HIP streams, as torch sees them
+            self.streams = [torch.cuda.ExternalStream(int(c.stream), device=dev) for c in self.contexts]
+            self.copy_stream = torch.cuda.Stream(device=dev)
 
-    def start(self, slot):
-        src = self.send[slot]
-        if not self.on_gpu:
-            self.stage[slot].copy_(src)
-            src = self.stage[slot]
+    def point(self, s, j, i):
+        self.contexts[i].set_skeleton_buffer(self.send[s].data_ptr() + j * self.capacity, self.capacity)
+
+    def start(self, s):
+        src = self.send[s]
+        if self.on_gpu:
+            cur = self.torch.cuda.current_stream()
+            for st in self.streams:
+                cur.wait_stream(st)      # the collective is ordered behind this round's decodes
+        else:
+            self.stage[s].copy_(src)     # the caller has waited for the contexts
+            src = self.stage[s]
         gl = None
         if self.rank == self.dst:
-            gl = list(self.recv[slot].view(self.world, self.capacity).unbind(0))
-        self.work[slot] = self.dist.gather(src, gather_list=gl, dst=self.dst, group=self.group, async_op=True)
+            gl = list(self.recv[s].view(self.world, -1).unbind(0))
+        self.work[s] = self.dist.gather(src, gather_list=gl, dst=self.dst, group=self.group, async_op=True)
 
-    def finish(self, slot):
-        work, self.work[slot] = self.work[slot], None
+    def finish(self, s):
+        work, self.work[s] = self.work[s], None
         if work is None:
             return None
-        work.wait()
         out = None
         if self.on_gpu:
+            # wait() orders a stream behind the collective; a stream of its own keeps the host
+            # wait below from also waiting for the decodes queued since
+            with self.torch.cuda.stream(self.copy_stream):
+                work.wait()
+                if self.rank == self.dst:
+                    self.host[s].copy_(self.recv[s], non_blocking=True)
+            self.copy_stream.synchronize()
             if self.rank == self.dst:
-                self.host[slot].copy_(self.recv[slot], non_blocking=True)
-            # wait() only orders the current stream behind the collective: the host has to
-            # wait too before the send buffer is handed back to the decode stream
-            self.torch.cuda.current_stream().synchronize()
+                out = self.host[s].numpy()
+        else:
+            work.wait()
             if self.rank == self.dst:
-                out = self.host[slot].numpy()
-        elif self.rank == self.dst:
-            out = self.recv[slot].numpy()
-        return None if out is None else out.reshape(self.world, self.capacity)
+                out = self.recv[s].numpy()
+        return None if out is None else out.reshape(self.world, self.n, self.capacity)
 
     @staticmethod
     def results(rows):
-        """Blobs of all ranks -> one result dict in image order (connections are not part
-        of the exchange: ``conns`` is empty and ``limb_count`` zero)."""
-        parts = []
-        for r, row in enumerate(rows):
-            need = int(np.ascontiguousarray(row[:64]).view(np.int64)[5])
-            if need:
-                raise ValueError('rank %d: its skeleton blob needs %d bytes, the gather capacity is %d'
-                                 % (r, need, row.size))
-            parts.append(unpack_blob(row))
-        return concat_results(parts)
+        """``finish``'s array -> one result dict per slice (= per step of the round), each
+        with the images of all ranks in image order (connections are not part of the
+        exchange: ``conns`` is empty and ``limb_count`` zero)."""
+        out = []
+        for i in range(rows.shape[1]):
+            parts = []
+            for r in range(rows.shape[0]):
+                row = rows[r, i]
+                need = int(np.ascontiguousarray(row[:64]).view(np.int64)[5])
+                if need:
+                    raise ValueError('rank %d: its skeleton blob needs %d bytes, the gather capacity is %d'
+                                     % (r, need, row.size))
+                parts.append(unpack_blob(row))
+            out.append(concat_results(parts))
+        return out

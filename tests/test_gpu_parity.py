@@ -321,7 +321,7 @@ def test_skeleton_buffer_holds_peaks_and_persons(pdec):
     buf = torch.full((1 << 16,), 255, dtype=torch.uint8, device='cuda')
     eng.ctx.set_skeleton_buffer(buf.data_ptr(), buf.numel())
     res = eng.decode_batch(heat, paf).packed
-    got = sharding.SkeletonGather.results(buf.cpu().numpy()[None])
+    got = sharding.SkeletonGather.results(buf.cpu().numpy()[None, None])[0]
     for key in ('part_count', 'person_count', 'status', 'peaks', 'persons'):
         assert np.array_equal(got[key], res[key]), key
     assert len(got['conns']) == 0 and not got['limb_count'].any() and len(res['conns']) > 0
@@ -335,6 +335,6 @@ def test_skeleton_buffer_holds_peaks_and_persons(pdec):
     assert need == _ffi.res_layout(4)[4] + len(res['peaks']) * 16 + len(res['persons']) * 160
     assert np.all(raw[small:] == 255)
     with pytest.raises(ValueError):
-        sharding.SkeletonGather.results(raw[None])
+        sharding.SkeletonGather.results(raw[None, None])
     eng.ctx.set_skeleton_buffer(None, 0)
     eng.close()

@@ -141,7 +141,8 @@ if rank == 0:
 else:
     assert out is None
 
-# the per-step exchange of the bench: skeleton buffers (no connection lists), two slots in flight
+# the exchange of the bench: skeleton buffers (no connection lists), one gather per round of
+# two contexts, two rounds in flight
 import torch
 class FakeCtx:
     def set_skeleton_buffer(self, ptr, cap):
@@ -149,36 +150,35 @@ class FakeCtx:
 ctxs = [FakeCtx(), FakeCtx()]
 cap = 1 << 15
 g = sharding.SkeletonGather(ctxs, cap, device=torch.device('cpu'))
-assert all(c.cap == cap and c.ptr == t.data_ptr() for c, t in zip(ctxs, g.send))
-def skeleton(seed):
-    r = _fake_results(hi - lo, seed)
+def skeleton(n, seed):
+    r = _fake_results(n, seed)
     r['conns'] = r['conns'][:0]
     r['limb_count'] = np.zeros_like(r['limb_count'])
     return r
-for slot in (0, 1):
-    blob = sharding.pack_blob(skeleton(70 + 10 * slot + rank))
-    g.send[slot][:blob.size] = torch.from_numpy(blob)
-    g.start(slot)
-for slot in (0, 1):
-    rows = g.finish(slot)
+for s in (0, 1):
+    for i in range(2):
+        g.point(s, i, i)
+    assert [c.ptr for c in ctxs] == [g.send[s].data_ptr(), g.send[s].data_ptr() + cap] and ctxs[0].cap == cap
+    for i in range(2):          # what the pack kernels of the two contexts would write
+        blob = sharding.pack_blob(skeleton(hi - lo, 70 + 10 * s + 3 * i + rank))
+        g.send[s][i * cap:i * cap + blob.size] = torch.from_numpy(blob)
+    g.start(s)
+for s in (0, 1):
+    rows = g.finish(s)
     if rank == 0:
+        assert rows.shape == (2, 2, cap)
         got = sharding.SkeletonGather.results(rows)
         sizes = [sharding.shard_range(9, 2, r) for r in range(2)]
-        want = []
-        for r, (a, b) in enumerate(sizes):
-            w = _fake_results(b - a, 70 + 10 * slot + r)
-            w['conns'] = w['conns'][:0]
-            w['limb_count'] = np.zeros_like(w['limb_count'])
-            want.append(w)
-        want = sharding.concat_results(want)
-        assert got['B'] == 9 and len(got['conns']) == 0
-        for k in ('part_count', 'person_count', 'peaks', 'persons'):
-            assert np.array_equal(got[k], want[k]), k
+        for i in range(2):
+            want = sharding.concat_results([skeleton(b - a, 70 + 10 * s + 3 * i + r) for r, (a, b) in enumerate(sizes)])
+            assert got[i]['B'] == 9 and len(got[i]['conns']) == 0
+            for k in ('part_count', 'person_count', 'peaks', 'persons'):
+                assert np.array_equal(got[i][k], want[k]), k
     else:
         assert rows is None
 if rank == 0:
-    bad = g.recv[0].numpy().reshape(2, cap).copy()
-    bad[1, :64].view(np.int64)[5] = 123456
+    bad = g.recv[0].numpy().reshape(2, 2, cap).copy()
+    bad[1, 0, :64].view(np.int64)[5] = 123456
     try:
         sharding.SkeletonGather.results(bad)
         raise SystemExit('a truncated blob was accepted')
