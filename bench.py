@@ -58,12 +58,6 @@ def main():
     # PD_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL gather of the skeleton buffers)
     # with a single rank, which is how that path is rehearsed on a one-GPU box
     use_dist = world > 1 or os.environ.get('PD_BENCH_FORCE_DIST') == '1'
-    if use_dist:
-        # With a process group alive, replaying the captured launch graph ended in a GPU
-        # memory fault on this stack (ROCm 7.2 / torch 2.10, first or second replay, while
-        # the process group's watchdog thread polls its events); eager launches do not.
-        # The contexts are created without graph replay: about 15 % slower per GPU.
-        os.environ['PD_NO_GRAPH'] = '1'
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     elif use_dist:
@@ -91,6 +85,8 @@ def main():
     while gather_cap < B * 4096:
         gather_cap <<= 1
 
+    # (contexts that are given a skeleton buffer launch eagerly: graph replay next to a live
+    # process group faulted on this stack, see pd_set_skeleton_buffer)
     GATHER_DEPTH = 2   # decodes per context between two gathers
     gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap, depth=GATHER_DEPTH) if use_dist else None
 

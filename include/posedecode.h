@@ -208,7 +208,8 @@ int pd_debug_smoothed(pd_ctx* ctx, double* out);
  * (peaks and person rows are all evaluate.py:44-74 reads).  header[5] != 0 means the
  * buffer was too small for the payload (header[5] = bytes needed); the header and the
  * count tables are always written.  NULL removes the buffer.  The buffer belongs to the
- * context's stream until the results have been waited for.  No counterpart in the
+ * context's stream until the results have been waited for.  A context that was given a
+ * buffer launches its kernels eagerly from then on (no graph replay).  No counterpart in the
  * reference: the reference is single-process. */
 int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t capacity);
 

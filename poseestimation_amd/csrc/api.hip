@@ -422,6 +422,18 @@ extern "C" int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t ca
     }
     ctx->skel_dst = (unsigned char*)device_ptr;
     ctx->skel_cap = device_ptr ? (size_t)capacity : 0;
+    if (device_ptr && ctx->use_graph) {
+        // A skeleton buffer means a multi-GPU job, i.e. a live process group in this
+        // process.  Replaying a captured launch graph next to one ended in GPU memory
+        // faults (ROCm 7.2, RCCL 2.26, first or second replay); eager launches never did.
+        // Such a context therefore launches eagerly from now on.
+        ctx->use_graph = 0;
+        if (ctx->graph_exec) {
+            PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            PD_HIP(ctx, hipGraphExecDestroy(ctx->graph_exec));
+            ctx->graph_exec = nullptr;
+        }
+    }
     return PD_OK;
 }
 
