@@ -116,9 +116,12 @@ def main():
                 rows = gather.finish(s)
                 last = rows if rows is not None else last
             k = min(n * GATHER_DEPTH, nsteps - done)
+            # the contexts' launcher threads issue the (eager) kernel launches in parallel
             for j in range(k):
-                gather.point(s, j, j % n)
-                engs[j % n].enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
+                engs[j % n].ctx.submit(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, H, W, 0.1, 0.05,
+                                       gather.slice_ptr(s, j), gather.capacity)
+            for e in engs:
+                e.ctx.flush()
             gather.start(s)
             pending[s] = True
             done += k
@@ -142,7 +145,9 @@ def main():
     ROOF_STAGE = 'filter'
     for e in engs:
         e.ctx.profile(stages=[ROOF_STAGE])
-    run(3 * len(engs))     # every context reaches its captured launch graph (third identical call)
+    # every context reaches its captured launch graph (third identical call); with a process
+    # group, the first gathers also set up RCCL's channels and the launcher threads
+    run(3 * len(engs) if gather is None else 8 * len(engs) * GATHER_DEPTH)
     last = run(args.warmup)
     for e in engs:
         e.ctx.profile_read()

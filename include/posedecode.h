@@ -202,6 +202,19 @@ int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);
  * sigma = 3), (B, 18, H, W) float64; test hook for the filter alone. */
 int pd_debug_smoothed(pd_ctx* ctx, double* out);
 
+/* pd_decode_batch on device-resident inputs, issued by a launcher thread that belongs to
+ * the context: the call only queues the request and returns, so one host thread can keep
+ * several contexts busy while their kernels are being launched in parallel (a decode is
+ * about fifteen launches).  skeleton_ptr, when not NULL, is installed with
+ * pd_set_skeleton_buffer before the decode.  Requests of one context run in order.
+ * pd_flush waits until every queued request has been launched (not: executed) and
+ * returns the first error since the last flush; no other entry point of the context
+ * may be called between pd_submit and the pd_flush that follows it.  No counterpart in
+ * the reference (single-threaded Python). */
+int pd_submit(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H, int W,
+              double thre1, double thre2, void* skeleton_ptr, uint64_t skeleton_capacity);
+int pd_flush(pd_ctx* ctx);
+
 /* A caller-owned device buffer that receives, with every pd_pack (so with every decode),
  * a second copy of the packed results without the connection lists: the layout of the
  * result buffer with n_conns = 0 and a zero limb table -- what a multi-GPU job gathers

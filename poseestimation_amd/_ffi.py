@@ -21,7 +21,7 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush']
 
 STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells', 'filter_border']
 
@@ -124,6 +124,8 @@ def lib():
     L.pd_profile_stages.argtypes = [vp, C.c_uint32]
     L.pd_filter_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.pd_set_skeleton_buffer.argtypes = [vp, vp, C.c_uint64]
+    L.pd_submit.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, dbl, dbl, vp, C.c_uint64]
+    L.pd_flush.argtypes = [vp]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -315,6 +317,15 @@ class Context:
     def set_skeleton_buffer(self, device_ptr, capacity):
         """Device buffer that receives peaks + person rows (no connections) with every pack."""
         self.check(self.L.pd_set_skeleton_buffer(self._h, device_ptr, capacity))
+
+    def submit(self, heat_ptr, paf_ptr, B, h, w, H, W, thre1, thre2, skeleton_ptr=None, skeleton_capacity=0):
+        """Queue a decode of device-resident inputs for the context's launcher thread."""
+        self.check(self.L.pd_submit(self._h, heat_ptr, paf_ptr, B, h, w, H, W, thre1, thre2, skeleton_ptr,
+                                    skeleton_capacity))
+
+    def flush(self):
+        """Wait until every queued decode has been launched; raises its first error."""
+        self.check(self.L.pd_flush(self._h))
 
     def sync(self):
         """Wait for everything queued on the context's stream; raises on a decode error."""

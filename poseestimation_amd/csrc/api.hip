@@ -102,7 +102,6 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     CR(dev_alloc(ctx, (void**)&ctx->persons, B * (size_t)cfg->max_persons * 20 * sizeof(double)));
     CR(dev_alloc(ctx, (void**)&ctx->person_count, B * sizeof(int32_t)));
     CR(dev_alloc(ctx, (void**)&ctx->status, B * sizeof(int32_t)));
-    CR(dev_alloc(ctx, (void**)&ctx->pack_off, (3 * (B + 1) + 4) * sizeof(int64_t)));
     {
         const ResLayout lay = pd_res_layout((int)B);
         ctx->res_cap = lay.off_payload + B * PD_N_PARTS * PK * sizeof(pd_peak) + B * PD_N_LIMBS * PK * sizeof(pd_conn) +
@@ -125,8 +124,24 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     return PD_OK;
 }
 
+static void stop_worker(pd_ctx* ctx) {
+    if (!ctx->worker) return;
+    {
+        std::lock_guard<std::mutex> lock(*ctx->wk_mu);
+        ctx->wk_stop = 1;
+    }
+    ctx->wk_cv->notify_all();
+    ctx->worker->join();
+    delete ctx->worker;
+    delete ctx->wk_jobs;
+    delete ctx->wk_cv;
+    delete ctx->wk_mu;
+    ctx->worker = nullptr;
+}
+
 extern "C" int pd_destroy(pd_ctx* ctx) {
     PD_CHECK_CTX(ctx);
+    stop_worker(ctx);
     (void)hipSetDevice(ctx->cfg.device_id);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void* ptrs[] = {ctx->stage_heat, ctx->stage_paf, ctx->full_heat, ctx->full_paf, ctx->tmp_up, ctx->tmp_in,
@@ -134,7 +149,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->tabs[1].f, ctx->tabs[2].i, ctx->tabs[2].f, ctx->raw, ctx->zero_block, ctx->pk_y,
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
-                    ctx->person_count, ctx->status, ctx->pack_off, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
+                    ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
                     ctx->heat_planar};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -708,6 +723,70 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     ctx->graph_prof_n = ctx->prof_n;
     PD_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
     return PD_OK;
+}
+
+// ---- pd_submit: the same decode, launched by a thread of the context's own -----------
+static void worker_main(pd_ctx* ctx) {
+    for (;;) {
+        SubmitJob job;
+        {
+            std::unique_lock<std::mutex> lock(*ctx->wk_mu);
+            ctx->wk_cv->wait(lock, [ctx] { return ctx->wk_stop || !ctx->wk_jobs->empty(); });
+            if (ctx->wk_jobs->empty()) return;  // stop requested and nothing left
+            job = ctx->wk_jobs->front();
+            ctx->wk_jobs->pop_front();
+            ctx->wk_busy = 1;
+        }
+        int rc = PD_OK;
+        if (ctx->wk_rc == PD_OK) {  // after a failure the rest of the queue is dropped
+            if (job.skel) rc = pd_set_skeleton_buffer(ctx, job.skel, job.skel_cap);
+            if (rc == PD_OK)
+                rc = pd_decode_batch(ctx, job.heat, job.paf, job.B, job.h, job.w, job.H, job.W, job.t1, job.t2, PD_MEM_DEVICE);
+        }
+        {
+            std::lock_guard<std::mutex> lock(*ctx->wk_mu);
+            if (rc != PD_OK && ctx->wk_rc == PD_OK) {
+                ctx->wk_rc = rc;
+                snprintf(ctx->wk_err, sizeof(ctx->wk_err), "%s", ctx->err);
+            }
+            ctx->wk_busy = 0;
+        }
+        ctx->wk_cv->notify_all();
+    }
+}
+
+extern "C" int pd_submit(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H, int W,
+                         double thre1, double thre2, void* skeleton_ptr, uint64_t skeleton_capacity) {
+    PD_CHECK_CTX(ctx);
+    if (!heat || !paf) PD_FAIL(ctx, PD_E_INVALID, "pd_submit: heat and paf are required");
+    if (!ctx->worker) {
+        ctx->wk_mu = new std::mutex();
+        ctx->wk_cv = new std::condition_variable();
+        ctx->wk_jobs = new std::deque<SubmitJob>();
+        ctx->wk_busy = ctx->wk_stop = 0;
+        ctx->wk_rc = PD_OK;
+        ctx->worker = new std::thread(worker_main, ctx);
+    }
+    SubmitJob job = {heat, paf, B, h, w, H, W, thre1, thre2, skeleton_ptr, skeleton_capacity};
+    {
+        std::lock_guard<std::mutex> lock(*ctx->wk_mu);
+        ctx->wk_jobs->push_back(job);
+    }
+    ctx->wk_cv->notify_all();
+    return PD_OK;
+}
+
+extern "C" int pd_flush(pd_ctx* ctx) {
+    PD_CHECK_CTX(ctx);
+    if (!ctx->worker) return PD_OK;
+    std::unique_lock<std::mutex> lock(*ctx->wk_mu);
+    ctx->wk_cv->wait(lock, [ctx] { return ctx->wk_jobs->empty() && !ctx->wk_busy; });
+    const int rc = ctx->wk_rc;
+    if (rc != PD_OK) {
+        snprintf(ctx->err, sizeof(ctx->err), "%s", ctx->wk_err);
+        ctx->wk_rc = PD_OK;
+    }
+    return rc;
 }
 
 void pd_prof_begin(pd_ctx* ctx, int stage) {

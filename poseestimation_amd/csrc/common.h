@@ -5,6 +5,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
 #include "../../include/posedecode.h"
 
 // Every floating-point result on this path must be the separately rounded
@@ -98,6 +103,16 @@ struct TableSlot {
     CubicTable ty, tx;
 };
 
+// One queued pd_submit call.
+struct SubmitJob {
+    const float* heat;
+    const float* paf;
+    int B, h, w, H, W;
+    double t1, t2;
+    void* skel;
+    uint64_t skel_cap;
+};
+
 struct pd_ctx {
     pd_config cfg;
     int mode, impl;
@@ -165,7 +180,6 @@ struct pd_ctx {
     int32_t* person_count;  // [B]
     int32_t* status;        // [B]
     // ---- packed results ----
-    int64_t* pack_off;  // [3][B+1] exclusive prefixes: peaks, conns, persons
     // one contiguous result buffer (see ResLayout) on the device and its pinned
     // host mirror; res_spec bytes are copied speculatively right behind the pack
     // kernel, the remainder (if any) once the totals are known
@@ -183,6 +197,15 @@ struct pd_ctx {
     int* prof_stage;
     double prof_ms[PD_N_STAGES];
     int64_t prof_cnt[PD_N_STAGES];
+    // ---- launcher thread of pd_submit ----
+    std::thread* worker;
+    std::mutex* wk_mu;
+    std::condition_variable* wk_cv;
+    std::deque<SubmitJob>* wk_jobs;
+    int wk_busy;   // a job is being launched
+    int wk_stop;
+    int wk_rc;     // first failure since the last pd_flush
+    char wk_err[512];
     // ---- HIP graph of the pd_decode_batch launch sequence ----
     int use_graph;
     hipGraphExec_t graph_exec;

@@ -109,7 +109,8 @@ class SkeletonGather:
     There are ``sets`` send buffers (two: the decodes of round r + 1 run while the gather
     of round r is in flight), each with ``contexts * depth`` slices of ``capacity`` bytes.
     Per round: ``point(s, j, i)`` directs the next decode of context ``i`` to slice ``j``
-    of set ``s`` and the caller enqueues that decode; ``start(s)`` launches the gather
+    of set ``s`` and the caller enqueues that decode (or hands ``slice_ptr(s, j)`` to
+    ``Context.submit`` and flushes the contexts); ``start(s)`` launches the gather
     behind the round's decodes (on the GPU the collective waits for the contexts' streams
     itself, the host does not block); ``finish(s)`` -- at the latest before set ``s`` is
     used again -- waits for it and returns, on ``dst``, a ``(world, slices, capacity)``
@@ -143,8 +144,12 @@ class SkeletonGather:
             self.streams = [torch.cuda.ExternalStream(int(c.stream), device=dev) for c in self.contexts]
             self.copy_stream = torch.cuda.Stream(device=dev)
 
+    def slice_ptr(self, s, j):
+        """Device address of slice ``j`` of set ``s`` (for ``Context.submit``)."""
+        return self.send[s].data_ptr() + j * self.capacity
+
     def point(self, s, j, i):
-        self.contexts[i].set_skeleton_buffer(self.send[s].data_ptr() + j * self.capacity, self.capacity)
+        self.contexts[i].set_skeleton_buffer(self.slice_ptr(s, j), self.capacity)
 
     def start(self, s):
         src = self.send[s]

@@ -338,3 +338,30 @@ def test_skeleton_buffer_holds_peaks_and_persons(pdec):
         sharding.SkeletonGather.results(raw[None, None])
     eng.ctx.set_skeleton_buffer(None, 0)
     eng.close()
+
+
+def test_submit_launches_from_the_context_thread(pdec):
+    """pd_submit / pd_flush: decodes queued for the context's launcher thread write the same
+    skeleton buffers as direct calls, in order, and errors surface at the flush."""
+    import torch
+    from poseestimation_amd import sharding, synth
+    H = W = 184
+    batches = [synth.batch(3, H, W, (1, 3), seed0=s, paf_order='xy') for s in (80, 90)]
+    want = [pdec.DecodeEngine(3, H, W, mode='D').decode_batch(h, p).packed for h, p in batches]
+    dev = [(torch.from_numpy(h).cuda(), torch.from_numpy(p).cuda()) for h, p in batches]
+    cap = 1 << 16
+    buf = torch.zeros(4 * cap, dtype=torch.uint8, device='cuda')
+    eng = pdec.DecodeEngine(max_batch=3, max_h=H, max_w=W, mode='D')
+    for j in range(4):
+        dh, dp = dev[j % 2]
+        eng.ctx.submit(dh.data_ptr(), dp.data_ptr(), 3, 23, 23, H, W, 0.1, 0.05, buf.data_ptr() + j * cap, cap)
+    eng.ctx.flush()
+    eng.ctx.sync()
+    got = sharding.SkeletonGather.results(buf.cpu().numpy().reshape(1, 4, cap))
+    for j in range(4):
+        for key in ('part_count', 'person_count', 'peaks', 'persons'):
+            assert np.array_equal(got[j][key], want[j % 2][key]), (j, key)
+    eng.ctx.submit(dev[0][0].data_ptr(), dev[0][1].data_ptr(), 4, 23, 23, H, W, 0.1, 0.05)   # batch 4 > max_batch 3
+    with pytest.raises(ValueError):
+        eng.ctx.flush()
+    eng.close()
