@@ -299,10 +299,16 @@ k_cells(CellArgs a) {
     for (int i = tid; i < 8 * hc; i += 256) byL[i] = a.by[i];
     for (int i = tid; i < hc; i += 256) regL[i] = a.regy[i];
     for (int i = tid; i < wc; i += 256) regL[hc + i] = a.regx[i];
-    float thr_lo, e2;
-    filter_slack(a.thr, a.absmax[b], &thr_lo, &e2);
-    if (part == 0 && tid == 0) a.slack[b] = make_float2(thr_lo, e2);
+    __shared__ float s_slack[2];
+    if (tid == 0) {  // a few dozen float64 instructions: one lane does them for the workgroup
+        float t, e;
+        filter_slack(a.thr, a.absmax[b], &t, &e);
+        s_slack[0] = t;
+        s_slack[1] = e;
+        if (part == 0) a.slack[b] = make_float2(t, e);
+    }
     __syncthreads();
+    const float thr_lo = s_slack[0];
     // thread = (cell column x, row lane): weights and clamped taps of the column stay in registers
     const int lanes = 256 / wc;  // wc <= 128
     const int x = tid % wc, rl = tid / wc;
@@ -644,14 +650,14 @@ k_verify(VerifyArgs a) {
     for (int base = blockIdx.x * 8; base < total; base += gridDim.x * 8) {
         const int ci = base + half;
         bool active = ci < total;
-        int Y = 0, X = 0, plane = 0;
+        int Y = 0, X = 0, plane = 0, plane_total = 0;
         double u13 = 0.0;
         if (active) {
             const int2 e = a.cand[segment_locate(s_pref, a.cand_seg_cap, ci)];
             plane = e.x;
             Y = e.y >> 16;
             X = e.y & 0xffff;
-            active = a.cand_count[plane] <= a.CK;  // overflowing planes are redone by the exact kernel
+            plane_total = a.cand_count[plane];  // only needed when the decision is written
         }
         if (active && l < 27) {
             const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
@@ -712,7 +718,7 @@ k_verify(VerifyArgs a) {
         const double s0 = __shfl(S, hb + 0), s1 = __shfl(S, hb + 1), s2 = __shfl(S, hb + 2),
                      s3 = __shfl(S, hb + 3), s4 = __shfl(S, hb + 4);
         const double score = __shfl(u13, hb + 13);
-        if (active && l == 0) {
+        if (active && l == 0 && plane_total <= a.CK) {  // overflowing planes are redone by the exact kernel
             if (s0 >= s1 && s0 >= s2 && s0 >= s3 && s0 >= s4 && s0 > a.thr) {
                 const int pos = atomicAdd(a.raw_count + plane, 1);
                 if (pos < a.PK) {
