@@ -150,7 +150,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
-                    ctx->heat_planar};
+                    ctx->heat_planar, ctx->paf_pairs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);

@@ -159,6 +159,8 @@ struct pd_ctx {
     float* absmax;                   // [B] max |heat| per image
     float* heat_planar;              // (B, 19, h, w) copy of the network heatmaps
     size_t heat_planar_cap;
+    float* paf_pairs;                // (B, 19, h, w, 2) copy of the PAFs, made for large batches only
+    size_t paf_pairs_cap;
     int cand_cap;                    // CK
     // ---- peaks ----
     int32_t* zero_block; // raw_count | cand_count + list counters | absmax + slack: cleared by one memset per decode

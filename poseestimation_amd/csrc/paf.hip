@@ -29,6 +29,7 @@ struct PairArgs {
     double* pair_score;
     int32_t* status;
     int per_image;  // workgroups per image
+    const float* pairs;  // (B, 19, h, w, 2) copy of the PAFs, or NULL: read the (h, w, 38) maps
 };
 
 // Two adjacent channels (ch, ch+1) of a (h, w, C) float32 map, bicubic at (Y, X);
@@ -37,6 +38,7 @@ struct PairArgs {
 // the two channels of one pixel from one 8-byte load (ch even, C even).
 __device__ __forceinline__ void bicubic2_at(const float* __restrict__ img, int h, int w, int C, int ch, int Y,
                                             int X, const float4* __restrict__ up, float* o0, float* o1) {
+    // C = floats between horizontally adjacent pixels, ch = offset of the channel pair
     const int x0 = pd_up8_ofs(X);
     const int y0 = pd_up8_ofs(Y);
     const float4 ac = up[pd_up8_phase(X)];
@@ -188,8 +190,12 @@ k_pair_scores(PairArgs a) {
                 double v0, v1;
                 if (a.src.kind == PD_SRC_LOWRES) {
                     float f0, f1;
-                    bicubic2_at(a.src.lo + (size_t)b * a.src.h * a.src.w * a.src.C, a.src.h, a.src.w, a.src.C,
-                                2 * k, iy, ix, s_up, &f0, &f1);
+                    if (a.pairs)
+                        bicubic2_at(a.pairs + ((size_t)b * PD_N_LIMBS + k) * a.src.h * a.src.w * 2, a.src.h, a.src.w, 2,
+                                    0, iy, ix, s_up, &f0, &f1);
+                    else
+                        bicubic2_at(a.src.lo + (size_t)b * a.src.h * a.src.w * a.src.C, a.src.h, a.src.w, a.src.C,
+                                    2 * k, iy, ix, s_up, &f0, &f1);
                     v0 = (double)f0;
                     v1 = (double)f1;
                 } else {
@@ -398,6 +404,25 @@ k_match(MatchArgs a) {
     if (lane == 0) *out_count = count;
 }
 
+// (B, h, w, 38) -> (B, 19, h, w, 2): the two channels of a limb side by side, pixels of a
+// row contiguous, so that the four horizontal taps of a sample share a cache line instead
+// of sitting 152 bytes apart.  Through LDS so that both sides are coalesced.
+#define PP_PIX 128
+__global__ void __launch_bounds__(256)
+k_paf_pairs(const float* __restrict__ lo, int npix, float* __restrict__ out) {
+    __shared__ float tile[PP_PIX * PD_CH_PAF];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int p0 = blockIdx.x * PP_PIX;
+    const int np = min(PP_PIX, npix - p0);
+    const float* src = lo + ((size_t)b * npix + p0) * PD_CH_PAF;
+    for (int i = tid; i < np * PD_CH_PAF; i += 256) tile[i] = src[i];
+    __syncthreads();
+    float2* dst = (float2*)out + (size_t)b * PD_N_LIMBS * npix + p0;
+    for (int k = 0; k < PD_N_LIMBS; ++k)
+        for (int i = tid; i < np; i += 256)
+            dst[(size_t)k * npix + i] = make_float2(tile[i * PD_CH_PAF + 2 * k], tile[i * PD_CH_PAF + 2 * k + 1]);
+}
+
 int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     PairArgs a;
     a.src = pd_paf_source(ctx);
@@ -416,7 +441,25 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     if (per_image > 64) per_image = 64;
     per_image = (per_image + 7) / 8 * 8;  // the XCD swizzle needs a grid that is a multiple of 8
     a.per_image = per_image;
+    // Maps that fit the caches are sampled where they lie; beyond that every tap of every
+    // sample would come from memory as a line of its own, and the pair-planar copy pays
+    a.pairs = nullptr;
+    const size_t paf_bytes = sizeof(float) * (size_t)ctx->B * ctx->h * ctx->w * PD_CH_PAF;
+    if (ctx->src_kind == PD_SRC_LOWRES && paf_bytes > ((size_t)64 << 20)) {
+        if (ctx->paf_pairs_cap < paf_bytes) {
+            PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->paf_pairs) PD_HIP(ctx, hipFree(ctx->paf_pairs));
+            ctx->paf_pairs = nullptr;
+            ctx->paf_pairs_cap = 0;
+            PD_HIP(ctx, hipMalloc(&ctx->paf_pairs, paf_bytes));
+            ctx->paf_pairs_cap = paf_bytes;
+        }
+        a.pairs = ctx->paf_pairs;
+    }
     pd_prof_begin(ctx, PD_STAGE_PAIRS);
+    if (a.pairs)
+        hipLaunchKernelGGL(k_paf_pairs, dim3((ctx->h * ctx->w + PP_PIX - 1) / PP_PIX, ctx->B), dim3(256), 0, ctx->stream,
+                           ctx->lo_paf, ctx->h * ctx->w, ctx->paf_pairs);
     hipLaunchKernelGGL(k_pair_scores, dim3(per_image * ctx->B), dim3(256), 0, ctx->stream, a);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
