@@ -145,14 +145,17 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
     (void)hipSetDevice(ctx->cfg.device_id);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void* ptrs[] = {ctx->stage_heat, ctx->stage_paf, ctx->full_heat, ctx->full_paf, ctx->tmp_up, ctx->tmp_in,
-                    ctx->tmp_smooth, ctx->tmp_smooth2, ctx->tabs[0].i, ctx->tabs[0].f, ctx->tabs[1].i,
-                    ctx->tabs[1].f, ctx->tabs[2].i, ctx->tabs[2].f, ctx->raw, ctx->zero_block, ctx->pk_y,
+                    ctx->tmp_smooth, ctx->tmp_smooth2, ctx->raw, ctx->zero_block, ctx->pk_y,
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
                     ctx->heat_planar, ctx->paf_pairs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (TableSlot& t : ctx->tabs) {
+        if (t.i) (void)hipFree(t.i);
+        if (t.f) (void)hipFree(t.f);
+    }
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->res_host) (void)hipHostFree(ctx->res_host);
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
@@ -333,31 +336,40 @@ extern "C" int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* he
         if (hs[m] < 1 || ws[m] < 1 || crop_h[m] < 1 || crop_w[m] < 1 || crop_h[m] > 8 * hs[m] || crop_w[m] > 8 * ws[m])
             PD_FAIL(ctx, PD_E_INVALID, "pd_upsample_avg: scale %d: crop %dx%d of x8 map of %dx%d", m, crop_h[m], crop_w[m], hs[m], ws[m]);
     }
+    if (n_scales > PD_MAX_SCALES) PD_FAIL(ctx, PD_E_INVALID, "pd_upsample_avg: at most %d scales", PD_MAX_SCALES);
     rc = ensure_full(ctx, B, H, W, true, true);
     if (rc != PD_OK) return rc;
+    // the x8 maps of all scales of one family (19 or 38 channels) are alive together, so
+    // that the average is formed in one pass that writes every output once
+    size_t n_lo_all = 0, n_up_all = 0;
     for (int m = 0; m < n_scales; ++m) {
-        const size_t n_lo = (size_t)B * hs[m] * ws[m];
-        const size_t n_up = (size_t)B * 64 * hs[m] * ws[m];
-        rc = ensure(ctx, (void**)&ctx->tmp_up, &ctx->tmp_up_cap, n_up * PD_CH_PAF * sizeof(float));
-        if (rc != PD_OK) return rc;
-        for (int which = 0; which < 2; ++which) {
-            const int C = which == 0 ? PD_CH_HEAT : PD_CH_PAF;
-            const float* src = which == 0 ? heat[m] : paf[m];
-            double* dst = which == 0 ? ctx->full_heat : ctx->full_paf;
-            if (mem == PD_MEM_HOST) {
-                float** st = which == 0 ? &ctx->stage_heat : &ctx->stage_paf;
-                size_t* cap = which == 0 ? &ctx->stage_heat_cap : &ctx->stage_paf_cap;
-                rc = ensure(ctx, (void**)st, cap, n_lo * C * sizeof(float));
-                if (rc != PD_OK) return rc;
-                PD_HIP(ctx, hipMemcpyAsync(*st, src, n_lo * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-                src = *st;
+        n_lo_all += (size_t)B * hs[m] * ws[m];
+        n_up_all += (size_t)B * 64 * hs[m] * ws[m];
+    }
+    rc = ensure(ctx, (void**)&ctx->tmp_up, &ctx->tmp_up_cap, n_up_all * PD_CH_PAF * sizeof(float));
+    if (rc != PD_OK) return rc;
+    for (int which = 0; which < 2; ++which) {
+        const int C = which == 0 ? PD_CH_HEAT : PD_CH_PAF;
+        const float* const* given = which == 0 ? heat : paf;
+        double* dst = which == 0 ? ctx->full_heat : ctx->full_paf;
+        const float* srcs[PD_MAX_SCALES];
+        if (mem == PD_MEM_HOST) {
+            float** st = which == 0 ? &ctx->stage_heat : &ctx->stage_paf;
+            size_t* cap = which == 0 ? &ctx->stage_heat_cap : &ctx->stage_paf_cap;
+            rc = ensure(ctx, (void**)st, cap, n_lo_all * C * sizeof(float));
+            if (rc != PD_OK) return rc;
+            size_t off = 0;
+            for (int m = 0; m < n_scales; ++m) {
+                const size_t cnt = (size_t)B * hs[m] * ws[m] * C;
+                PD_HIP(ctx, hipMemcpyAsync(*st + off, given[m], cnt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                srcs[m] = *st + off;
+                off += cnt;
             }
-            rc = pd_launch_resize_up8(ctx, src, C, B, hs[m], ws[m], ctx->tmp_up);
-            if (rc != PD_OK) return rc;
-            rc = pd_launch_resize_accum(ctx, ctx->tmp_up, C, B, 8 * hs[m], 8 * ws[m], crop_h[m], crop_w[m], dst, H,
-                                        W, (float)n_scales, m == 0);
-            if (rc != PD_OK) return rc;
+        } else {
+            for (int m = 0; m < n_scales; ++m) srcs[m] = given[m];
         }
+        rc = pd_launch_upsample_avg(ctx, n_scales, srcs, C, B, hs, ws, crop_h, crop_w, ctx->tmp_up, dst, H, W);
+        if (rc != PD_OK) return rc;
     }
     ctx->src_kind = PD_SRC_FULLRES;
     ctx->B = B;

@@ -19,6 +19,7 @@
 #define PD_GR 12      // Gaussian radius: int(4.0 * 3 + 0.5)
 #define PD_GTAPS 13   // centre + 12 symmetric pairs
 #define PD_MID 10     // sample points per limb candidate (utils/postprocess.py:79)
+#define PD_MAX_SCALES 8  // scales of one pd_upsample_avg call
 
 enum { PD_SRC_NONE = 0, PD_SRC_LOWRES = 1, PD_SRC_FULLRES = 2 };
 
@@ -101,6 +102,8 @@ struct TableSlot {
     float* f;
     size_t cap;
     CubicTable ty, tx;
+    int key[4];      // hs, ws, Hd, Wd the tables were built for
+    double scale[2];
 };
 
 // One queued pd_submit call.
@@ -143,7 +146,7 @@ struct pd_ctx {
 
     // bicubic tap tables on the device: slot 0 = x8 tables of the fused low-res
     // source, slot 1 / 2 = first / second resize of pd_upsample_avg
-    TableSlot tabs[3];
+    TableSlot tabs[2 + PD_MAX_SCALES];  // 0: x8 of the fused source, 1: spare, 2 + m: second resize of scale m
     int tab_h, tab_w, tab_H, tab_W;  // what the slot-0 tables were built for
 
     // ---- candidate filter (float32 composite of bicubic x8 and Gaussian) ----
@@ -294,5 +297,8 @@ int pd_launch_planar_to_hwc(pd_ctx* ctx, const double* src, int C, int B, int H,
 int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W);
 void pd_host_cubic_table(int src_len, int dst_len, double scale, int32_t* ofs, float* coef);
 void pd_up8_fill(Up8* u);
+int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
+                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, float* up, double* dst,
+                           int H, int W);
 MapSource pd_heat_source(const pd_ctx* ctx);
 MapSource pd_paf_source(const pd_ctx* ctx);

@@ -55,6 +55,9 @@ static int upload_tables(pd_ctx* ctx, int hs, int ws, int Hd, int Wd, double sy,
     CubicTable* ty = &slot->ty;
     CubicTable* tx = &slot->tx;
     const size_t need = (size_t)Hd + Wd;
+    if (slot->i && slot->key[0] == hs && slot->key[1] == ws && slot->key[2] == Hd && slot->key[3] == Wd &&
+        slot->scale[0] == sy && slot->scale[1] == sx)
+        return PD_OK;  // still valid
     if (*cap < need) {
         if (*d_i) PD_HIP(ctx, hipFree(*d_i));
         if (*d_f) PD_HIP(ctx, hipFree(*d_f));
@@ -77,6 +80,12 @@ static int upload_tables(pd_ctx* ctx, int hs, int ws, int Hd, int Wd, double sy,
     ty->coef = *d_f;
     tx->ofs = *d_i + Hd;
     tx->coef = *d_f + 4 * (size_t)Hd;
+    slot->key[0] = hs;
+    slot->key[1] = ws;
+    slot->key[2] = Hd;
+    slot->key[3] = Wd;
+    slot->scale[0] = sy;
+    slot->scale[1] = sx;
     return PD_OK;
 }
 
@@ -158,6 +167,161 @@ __global__ void k_planar_to_hwc(const double* __restrict__ src, int C, int H, in
     const int ch = (int)(i % C);
     const size_t px = i / C;
     dst[(size_t)b * n + i] = src[((size_t)b * C + ch) * (size_t)H * W + px];
+}
+
+// ---- x8 upsample, eight output rows per thread ------------------------------------------
+// Output rows 8j-4 .. 8j+3 draw on the same four source rows (j-2 .. j+1, clamped) and
+// differ only in the phase of their weights, so a thread forms the four horizontal sums of
+// its column once and combines them eight times.  Arithmetic per output as in k_resize_up.
+__global__ void __launch_bounds__(256)
+k_resize_up8(const float* __restrict__ src, int C, int hs, int ws, Up8 up, float* __restrict__ dst) {
+    __shared__ float4 s_up[8];
+    if (threadIdx.x < 8) s_up[threadIdx.x] = make_float4(up.c[threadIdx.x][0], up.c[threadIdx.x][1], up.c[threadIdx.x][2], up.c[threadIdx.x][3]);
+    __syncthreads();
+    const int Hd = 8 * hs, Wd = 8 * ws;
+    const int X = blockIdx.x * 256 + threadIdx.x;
+    if (X >= Wd) return;
+    const int j = blockIdx.y;                 // 0 .. hs
+    const int ch = blockIdx.z % C, b = blockIdx.z / C;
+    const int x0 = pd_up8_ofs(X);
+    const float4 ac = s_up[pd_up8_phase(X)];
+    const int xi0 = pd_clampi(x0, 0, ws - 1) * C, xi1 = pd_clampi(x0 + 1, 0, ws - 1) * C,
+              xi2 = pd_clampi(x0 + 2, 0, ws - 1) * C, xi3 = pd_clampi(x0 + 3, 0, ws - 1) * C;
+    const float* img = src + (size_t)b * hs * ws * C + ch;
+    float hsum[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* row = img + (size_t)pd_clampi(j - 2 + k, 0, hs - 1) * ws * C;
+        hsum[k] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
+    }
+    float* out = dst + ((size_t)b * C + ch) * (size_t)Hd * Wd + X;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int d = 8 * j - 4 + p;
+        if (d >= 0 && d < Hd)
+            out[(size_t)d * Wd] = ((hsum[0] * up.c[p][0] + hsum[1] * up.c[p][1]) + hsum[2] * up.c[p][2]) + hsum[3] * up.c[p][3];
+    }
+}
+
+// ---- second resize of every scale + average, one pass -------------------------------------
+// out = ((0 + v_0 / n) + v_1 / n) + ..  with v_m the crop of scale m's x8 map resized to
+// (H, W) (predict.py:64-65, 71-72): float32 division, float64 accumulation in scale order.
+struct ScaleSrc {
+    const float* up;   // planar (B, C, Hs, Ws) float32
+    int Hs, Ws, crop_h, crop_w, identity;
+    CubicTable ty, tx;
+};
+struct AvgArgs {
+    ScaleSrc s[PD_MAX_SCALES];
+    int n_scales, C, H, W;
+    float n_div;
+    double* dst;       // planar (B, C, H, W)
+};
+
+#define AVG_CH 8  // channels per thread: taps and weights of a pixel are set up once per scale for all of them
+__global__ void __launch_bounds__(256)
+k_resize_avg(AvgArgs a) {
+    // a workgroup covers a 32 x 8 tile of outputs, so that the rows of the x8 maps it draws
+    // on are re-read from the first-level cache
+    const size_t n = (size_t)a.H * a.W;
+    // Workgroup i runs on XCD i % 8, each with an L2 of its own: XCD x takes the x-th eighth
+    // of the tiles in row-major order, so that tiles sharing rows and lines share an L2.
+    const int tiles_x = (a.W + 31) / 32, tiles = tiles_x * ((a.H + 7) / 8);
+    const int per_xcd = (tiles + 7) / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile >= tiles) return;
+    const int X = (tile % tiles_x) * 32 + (threadIdx.x & 31);
+    const int Y = (tile / tiles_x) * 8 + (threadIdx.x >> 5);
+    if (X >= a.W || Y >= a.H) return;
+    const size_t i = (size_t)Y * a.W + X;
+    const int ch0 = blockIdx.y * AVG_CH, b = blockIdx.z;
+    const int nch = min(AVG_CH, a.C - ch0);
+    double acc[AVG_CH];
+#pragma unroll
+    for (int c = 0; c < AVG_CH; ++c) acc[c] = 0.0;
+    for (int m = 0; m < a.n_scales; ++m) {
+        const ScaleSrc& sc = a.s[m];
+        const size_t plane = (size_t)sc.Hs * sc.Ws;
+        const float* p = sc.up + ((size_t)b * a.C + ch0) * plane;
+        if (sc.identity) {
+            const size_t o = (size_t)Y * sc.Ws + X;
+#pragma unroll
+            for (int c = 0; c < AVG_CH; ++c)
+                if (c < nch) acc[c] = acc[c] + (double)(p[c * plane + o] / a.n_div);
+        } else {
+            const int x0 = sc.tx.ofs[X], y0 = sc.ty.ofs[Y];
+            const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)X);
+            const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Y);
+            const int xi0 = pd_clampi(x0, 0, sc.crop_w - 1), xi1 = pd_clampi(x0 + 1, 0, sc.crop_w - 1),
+                      xi2 = pd_clampi(x0 + 2, 0, sc.crop_w - 1), xi3 = pd_clampi(x0 + 3, 0, sc.crop_w - 1);
+            int ro[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ro[k] = pd_clampi(y0 + k, 0, sc.crop_h - 1) * sc.Ws;
+#pragma unroll
+            for (int c = 0; c < AVG_CH; ++c) {
+                if (c < nch) {
+                    const float* q = p + c * plane;
+                    float hv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float* row = q + ro[k];
+                        hv[k] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
+                    }
+                    const float v = ((hv[0] * bc.x + hv[1] * bc.y) + hv[2] * bc.z) + hv[3] * bc.w;
+                    acc[c] = acc[c] + (double)(v / a.n_div);
+                }
+            }
+        }
+    }
+    double* out = a.dst + ((size_t)b * a.C + ch0) * n + i;
+#pragma unroll
+    for (int c = 0; c < AVG_CH; ++c)
+        if (c < nch) out[c * n] = acc[c];
+}
+
+// All scales of one map family (C = 19 or 38): srcs[m] is (B, hs[m], ws[m], C) on the
+// device; up holds the x8 maps of all scales one after the other.
+int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
+                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, float* up, double* dst,
+                           int H, int W) {
+    AvgArgs a;
+    memset(&a, 0, sizeof(a));
+    Up8 u8;
+    pd_up8_fill(&u8);
+    size_t off = 0;
+    for (int m = 0; m < n_scales; ++m) {
+        const int Hs = 8 * hs[m], Ws = 8 * ws[m];
+        ScaleSrc& sc = a.s[m];
+        sc.up = up + off;
+        sc.Hs = Hs;
+        sc.Ws = Ws;
+        sc.crop_h = crop_h[m];
+        sc.crop_w = crop_w[m];
+        sc.identity = crop_h[m] == H && crop_w[m] == W;
+        if (!sc.identity) {
+            int rc = upload_tables(ctx, crop_h[m], crop_w[m], H, W, -1.0, -1.0, &ctx->tabs[2 + m]);
+            if (rc != PD_OK) return rc;
+            sc.ty = ctx->tabs[2 + m].ty;
+            sc.tx = ctx->tabs[2 + m].tx;
+        }
+        pd_prof_begin(ctx, PD_STAGE_RESIZE);
+        hipLaunchKernelGGL(k_resize_up8, dim3((Ws + 255) / 256, hs[m] + 1, C * B), dim3(256), 0, ctx->stream, srcs[m], C,
+                           hs[m], ws[m], u8, up + off);
+        pd_prof_end(ctx);
+        off += (size_t)B * C * Hs * Ws;
+    }
+    a.n_scales = n_scales;
+    a.C = C;
+    a.H = H;
+    a.W = W;
+    a.n_div = (float)n_scales;
+    a.dst = dst;
+    const unsigned tiles = (unsigned)(((W + 31) / 32) * ((H + 7) / 8));
+    pd_prof_begin(ctx, PD_STAGE_RESIZE);
+    hipLaunchKernelGGL(k_resize_avg, dim3((tiles + 7) / 8 * 8, (C + AVG_CH - 1) / AVG_CH, B), dim3(256), 0, ctx->stream, a);
+    pd_prof_end(ctx);
+    PD_HIP(ctx, hipGetLastError());
+    return PD_OK;
 }
 
 int pd_launch_resize_up8(pd_ctx* ctx, const float* src, int C, int B, int hs, int ws, float* dst) {
