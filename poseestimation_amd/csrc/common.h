@@ -288,9 +288,6 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2);
 int pd_launch_match(pd_ctx* ctx);
 int pd_launch_parse(pd_ctx* ctx);
 int pd_launch_pack(pd_ctx* ctx);
-int pd_launch_resize_up8(pd_ctx* ctx, const float* src, int C, int B, int hs, int ws, float* dst);
-int pd_launch_resize_accum(pd_ctx* ctx, const float* up, int C, int B, int Hs, int Ws, int crop_h,
-                           int crop_w, double* dst, int H, int W, float n_scales, int first);
 int pd_launch_hwc_to_planar(pd_ctx* ctx, const void* src, int dtype, int Csrc, int Cdst, int B, int H,
                             int W, double* dst);
 int pd_launch_planar_to_hwc(pd_ctx* ctx, const double* src, int C, int B, int H, int W, double* dst);

@@ -102,52 +102,6 @@ int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W) {
     return PD_OK;
 }
 
-// ---- x8 upsample: (B, hs, ws, C) float32 -> planar (B, C, Hd, Wd) float32 ----------
-__global__ void k_resize_up(const float* __restrict__ src, int C, int hs, int ws, CubicTable ty,
-                            CubicTable tx, float* __restrict__ dst, int Hd, int Wd) {
-    const size_t n = (size_t)Hd * Wd;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int ch = blockIdx.y, b = blockIdx.z;
-    const int Y = (int)(i / Wd), X = (int)(i % Wd);
-    const float v = pd_bicubic_at(src + (size_t)b * hs * ws * C, hs, ws, C, ch, Y, X, ty, tx);
-    dst[((size_t)b * C + ch) * n + i] = v;
-}
-
-// ---- crop + resize to (H, W) + divide by the number of scales + float64 accumulate ----
-// src planar (B, C, Hs, Ws) float32, the crop window is its top-left crop_h x crop_w.
-__global__ void k_resize_accum(const float* __restrict__ src, int C, int Hs, int Ws, int crop_h,
-                               int crop_w, CubicTable ty, CubicTable tx, int identity,
-                               double* __restrict__ dst, int H, int W, float n_scales, int first) {
-    const size_t n = (size_t)H * W;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int ch = blockIdx.y, b = blockIdx.z;
-    const float* p = src + ((size_t)b * C + ch) * (size_t)Hs * Ws;
-    const int Y = (int)(i / W), X = (int)(i % W);
-    float v;
-    if (identity) {
-        v = p[(size_t)Y * Ws + X];
-    } else {
-        const int x0 = tx.ofs[X], y0 = ty.ofs[Y];
-        const float a0 = tx.coef[4 * X + 0], a1 = tx.coef[4 * X + 1], a2 = tx.coef[4 * X + 2],
-                    a3 = tx.coef[4 * X + 3];
-        const int xi0 = pd_clampi(x0, 0, crop_w - 1), xi1 = pd_clampi(x0 + 1, 0, crop_w - 1),
-                  xi2 = pd_clampi(x0 + 2, 0, crop_w - 1), xi3 = pd_clampi(x0 + 3, 0, crop_w - 1);
-        float hv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float* row = p + (size_t)pd_clampi(y0 + k, 0, crop_h - 1) * Ws;
-            hv[k] = ((row[xi0] * a0 + row[xi1] * a1) + row[xi2] * a2) + row[xi3] * a3;
-        }
-        v = ((hv[0] * ty.coef[4 * Y + 0] + hv[1] * ty.coef[4 * Y + 1]) + hv[2] * ty.coef[4 * Y + 2]) +
-            hv[3] * ty.coef[4 * Y + 3];
-    }
-    const double add = (double)(v / n_scales);  // float32 division, predict.py:71-72
-    double* q = dst + ((size_t)b * C + ch) * n + i;
-    *q = first ? 0.0 + add : *q + add;
-}
-
 __global__ void k_hwc_to_planar(const void* __restrict__ src, int dtype, int Csrc, int Cdst, int H, int W,
                                 double* __restrict__ dst) {
     const size_t n = (size_t)H * W;
@@ -172,7 +126,8 @@ __global__ void k_planar_to_hwc(const double* __restrict__ src, int C, int H, in
 // ---- x8 upsample, eight output rows per thread ------------------------------------------
 // Output rows 8j-4 .. 8j+3 draw on the same four source rows (j-2 .. j+1, clamped) and
 // differ only in the phase of their weights, so a thread forms the four horizontal sums of
-// its column once and combines them eight times.  Arithmetic per output as in k_resize_up.
+// its column once and combines them eight times.  Per output: the horizontal 4-tap sum of each source row, then the vertical 4-tap sum,
+// float32, multiplies and adds rounded separately.
 __global__ void __launch_bounds__(256)
 k_resize_up8(const float* __restrict__ src, int C, int hs, int ws, Up8 up, float* __restrict__ dst) {
     __shared__ float4 s_up[8];
@@ -319,39 +274,6 @@ int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, 
     const unsigned tiles = (unsigned)(((W + 31) / 32) * ((H + 7) / 8));
     pd_prof_begin(ctx, PD_STAGE_RESIZE);
     hipLaunchKernelGGL(k_resize_avg, dim3((tiles + 7) / 8 * 8, (C + AVG_CH - 1) / AVG_CH, B), dim3(256), 0, ctx->stream, a);
-    pd_prof_end(ctx);
-    PD_HIP(ctx, hipGetLastError());
-    return PD_OK;
-}
-
-int pd_launch_resize_up8(pd_ctx* ctx, const float* src, int C, int B, int hs, int ws, float* dst) {
-    const int Hd = 8 * hs, Wd = 8 * ws;
-    int rc = upload_tables(ctx, hs, ws, Hd, Wd, 0.125, 0.125, &ctx->tabs[1]);
-    if (rc != PD_OK) return rc;
-    const CubicTable ty = ctx->tabs[1].ty, tx = ctx->tabs[1].tx;
-    const size_t n = (size_t)Hd * Wd;
-    pd_prof_begin(ctx, PD_STAGE_RESIZE);
-    hipLaunchKernelGGL(k_resize_up, dim3((unsigned)((n + 255) / 256), C, B), dim3(256), 0, ctx->stream, src, C,
-                       hs, ws, ty, tx, dst, Hd, Wd);
-    pd_prof_end(ctx);
-    PD_HIP(ctx, hipGetLastError());
-    return PD_OK;
-}
-
-int pd_launch_resize_accum(pd_ctx* ctx, const float* up, int C, int B, int Hs, int Ws, int crop_h,
-                           int crop_w, double* dst, int H, int W, float n_scales, int first) {
-    CubicTable ty = {nullptr, nullptr}, tx = {nullptr, nullptr};
-    const int identity = (crop_h == H && crop_w == W);
-    if (!identity) {
-        int rc = upload_tables(ctx, crop_h, crop_w, H, W, -1.0, -1.0, &ctx->tabs[2]);
-        if (rc != PD_OK) return rc;
-        ty = ctx->tabs[2].ty;
-        tx = ctx->tabs[2].tx;
-    }
-    const size_t n = (size_t)H * W;
-    pd_prof_begin(ctx, PD_STAGE_RESIZE);
-    hipLaunchKernelGGL(k_resize_accum, dim3((unsigned)((n + 255) / 256), C, B), dim3(256), 0, ctx->stream, up, C,
-                       Hs, Ws, crop_h, crop_w, ty, tx, identity, dst, H, W, n_scales, first);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
