@@ -251,7 +251,8 @@ def main():
             out['parity_checked_images'] = ncpu
             out['parity_ok'] = bool(ok)
         print(json.dumps(out))
-    eng.close()
+    for e in engs:
+        e.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -365,3 +365,21 @@ def test_submit_launches_from_the_context_thread(pdec):
     with pytest.raises(ValueError):
         eng.ctx.flush()
     eng.close()
+
+
+@pytest.mark.parametrize('caps', [dict(max_peaks_per_part=2), dict(max_pairs_per_image=20), dict(max_persons=1)])
+def test_capacity_overflow_is_reported_not_truncated(pdec, caps):
+    """A context sized too small for an image raises (PD_E_OVERFLOW) when the results are
+    fetched; nothing is silently cut short.  The same batch decodes once the capacity fits."""
+    from poseestimation_amd import _ffi, synth
+    H = W = 184
+    heat, paf = synth.batch(2, H, W, 4, seed0=33, paf_order='xy')
+    full = dict(max_peaks_per_part=64, max_pairs_per_image=4000, max_persons=32)
+    good = pdec.DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='D', **full).decode_batch(heat, paf)
+    assert good.packed['person_count'].sum() >= 4
+    small = dict(full)
+    small.update(caps)
+    eng = pdec.DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='D', **small)
+    with pytest.raises(_ffi.DecodeOverflow):
+        eng.decode_batch(heat, paf)
+    eng.close()
