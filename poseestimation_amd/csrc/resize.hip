@@ -173,6 +173,7 @@ struct AvgArgs {
     double* dst;       // planar (B, C, H, W)
 };
 
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 #define AVG_CH 8  // channels per thread: taps and weights of a pixel are set up once per scale for all of them
 __global__ void __launch_bounds__(256)
 k_resize_avg(AvgArgs a) {
@@ -212,6 +213,10 @@ k_resize_avg(AvgArgs a) {
             int ro[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) ro[k] = pd_clampi(y0 + k, 0, sc.crop_h - 1) * sc.Ws;
+            // away from the left and right border the four taps are adjacent: one 16-byte load
+            // (4-byte aligned) instead of four loads -- the kernel is bound by the number of
+            // load instructions, not by their bytes
+            const bool adjacent = x0 >= 0 && x0 + 3 <= sc.crop_w - 1;
 #pragma unroll
             for (int c = 0; c < AVG_CH; ++c) {
                 if (c < nch) {
@@ -220,7 +225,12 @@ k_resize_avg(AvgArgs a) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float* row = q + ro[k];
-                        hv[k] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
+                        if (adjacent) {
+                            const float4u t = *(const float4u*)(row + x0);
+                            hv[k] = ((t.x * ac.x + t.y * ac.y) + t.z * ac.z) + t.w * ac.w;
+                        } else {
+                            hv[k] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
+                        }
                     }
                     const float v = ((hv[0] * bc.x + hv[1] * bc.y) + hv[2] * bc.z) + hv[3] * bc.w;
                     acc[c] = acc[c] + (double)(v / a.n_div);
