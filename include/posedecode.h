@@ -202,6 +202,12 @@ int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);
  * sigma = 3), (B, 18, H, W) float64; test hook for the filter alone. */
 int pd_debug_smoothed(pd_ctx* ctx, double* out);
 
+/* Graph replay of pd_decode_batch on device-resident inputs (on by default, off with
+ * PD_NO_GRAPH=1 in the environment at pd_create).  Turn it off in processes that also run
+ * a torch.distributed / RCCL process group: replaying a captured graph next to one ended
+ * in GPU memory faults (ROCm 7.2, RCCL 2.26); the Python wrapper does so by itself. */
+int pd_set_graph_replay(pd_ctx* ctx, int enable);
+
 /* pd_decode_batch on device-resident inputs, issued by a launcher thread that belongs to
  * the context: the call only queues the request and returns, so one host thread can keep
  * several contexts busy while their kernels are being launched in parallel (a decode is

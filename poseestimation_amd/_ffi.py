@@ -5,6 +5,7 @@ decode raises.  ctypes releases the GIL for the duration of every call.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -21,7 +22,7 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay']
 
 STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells', 'filter_border']
 
@@ -126,6 +127,7 @@ def lib():
     L.pd_set_skeleton_buffer.argtypes = [vp, vp, C.c_uint64]
     L.pd_submit.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, dbl, dbl, vp, C.c_uint64]
     L.pd_flush.argtypes = [vp]
+    L.pd_set_graph_replay.argtypes = [vp, i32]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -137,6 +139,14 @@ def lib():
 
 def _ptr(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _process_group_alive():
+    td = sys.modules.get('torch.distributed')
+    try:
+        return bool(td is not None and td.is_available() and td.is_initialized())
+    except Exception:
+        return False
 
 
 class Context:
@@ -153,6 +163,9 @@ class Context:
         if rc != PD_OK:
             raise RuntimeError('pd_create failed (%d): %s' % (rc, L.pd_last_error(None).decode()))
         self._h = h
+        if _process_group_alive():
+            # graph replay next to a live process group faulted the GPU on this stack
+            self.set_graph_replay(False)
         self.cfg = cfg
         self.L = L
 
@@ -313,6 +326,9 @@ class Context:
         ptrs = [C.c_void_p() for _ in range(6)]
         self.check(self.L.pd_packed_device(self._h, *[C.byref(p) for p in ptrs]))
         return [p.value for p in ptrs]
+
+    def set_graph_replay(self, enable):
+        self.check(self.L.pd_set_graph_replay(self._h, 1 if enable else 0))
 
     def set_skeleton_buffer(self, device_ptr, capacity):
         """Device buffer that receives peaks + person rows (no connections) with every pack."""

@@ -438,6 +438,18 @@ extern "C" int pd_debug_smoothed(pd_ctx* ctx, double* out) {
     return rc;
 }
 
+extern "C" int pd_set_graph_replay(pd_ctx* ctx, int enable) {
+    PD_CHECK_CTX(ctx);
+    ctx->use_graph = enable ? 1 : 0;
+    if (!enable && ctx->graph_exec) {
+        PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PD_HIP(ctx, hipGraphExecDestroy(ctx->graph_exec));
+        ctx->graph_exec = nullptr;
+    }
+    return PD_OK;
+}
+
 extern "C" int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t capacity) {
     PD_CHECK_CTX(ctx);
     if (device_ptr) {
