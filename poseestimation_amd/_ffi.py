@@ -163,11 +163,11 @@ class Context:
         if rc != PD_OK:
             raise RuntimeError('pd_create failed (%d): %s' % (rc, L.pd_last_error(None).decode()))
         self._h = h
+        self.cfg = cfg
+        self.L = L
         if _process_group_alive():
             # graph replay next to a live process group faulted the GPU on this stack
             self.set_graph_replay(False)
-        self.cfg = cfg
-        self.L = L
 
     def close(self):
         if self._h is not None:
