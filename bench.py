@@ -58,11 +58,24 @@ def main():
     # PD_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL gather of the skeleton buffers)
     # with a single rank, which is how that path is rehearsed on a one-GPU box
     use_dist = world > 1 or os.environ.get('PD_BENCH_FORCE_DIST') == '1'
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    elif use_dist:
-        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1,
-                                device_id=torch.device('cuda', local_rank))
+    if use_dist:
+        # RCCL writes a version banner to stdout when its first communicator comes up; stdout
+        # carries the JSON line only, so the banner is sent to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if world > 1:
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            else:
+                dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1,
+                                        device_id=torch.device('cuda', local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     B, H, W, people, desc = WORKLOADS[args.workload]
     if args.people:      # experiments only: a fixed number of people per image
