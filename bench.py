@@ -196,7 +196,7 @@ def main():
     if rank == 0:
         images = world * B * args.steps
         n, N = h * w, H * W
-        # Roofline kernel: k_cell_filter<true>, the float32 evaluation of the smoothed x8 map
+        # Roofline kernel: k_cell_filter, the float32 evaluation of the smoothed x8 map
         # and its non-maximum suppression (with k_cells, which picks the 8x8 cells it has
         # to visit, it stands for the reference's upsample + Gaussian + NMS pass over every
         # pixel of the 18 part channels).  Algorithmic bytes per image of that pass:
@@ -204,7 +204,7 @@ def main():
         # 18*N*4  =  72*n + 288*N.  The kernel itself touches a few percent of that, so the
         # fraction says how much faster than a materialising implementation at HBM peak
         # the stage runs, not how busy HBM is.
-        kname = 'k_cell_filter<true>'
+        kname = 'k_cell_filter'
         sm_ms, sm_n = roof_ms, roof_n
         if sm_n == 0:       # the exact streaming kernel ran alone (no filter tables for this geometry)
             kname = 'k_smooth_nms_stream'

@@ -189,7 +189,7 @@ enum {
     PD_STAGE_VERIFY = 8,     /* exact float64 verification of the candidates */
     PD_STAGE_PLANAR = 9,     /* (h, w, 19) -> planar copy of the heatmaps + max |v| */
     PD_STAGE_CELLS = 10,     /* active-cell scan at network resolution */
-    PD_STAGE_FILTER_BORDER = 11, /* candidate filter over the cells with border weights */
+    PD_STAGE_FILTER_BORDER = 11, /* unused: the border cells are part of PD_STAGE_FILTER */
     PD_N_STAGES = 12
 };
 int pd_profile(pd_ctx* ctx, int enable);

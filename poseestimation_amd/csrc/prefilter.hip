@@ -421,6 +421,7 @@ __device__ __forceinline__ int segment_locate(const int* pref, int seg_cap, int 
 
 struct FilterShared {
     float tile[KF_CELLS_PER_BLOCK][9][10];  // per cell: x-pass sums, source row q, output column i
+    __attribute__((aligned(16))) float wts[KF_CELLS_PER_BLOCK][72];  // per border cell: the weights of the pass at hand
     int2 cand[KF_LCAND];
     int n_cand;
     int base;
@@ -468,53 +469,47 @@ __device__ __forceinline__ void load_cell(const CellFilterArgs& a, int e, int r,
     }
 }
 
-// Workgroups of segment s = blockIdx.x % KF_NSEG share that segment's cells; every
-// wavefront takes six cells at a time (ten lanes per cell) and runs on its own: the
-// x-pass results cross lanes through a wave-private LDS tile, and the loads of the next
-// six cells are in flight while the current ones are evaluated.
+// One pass over one kind of cell of segment `seg`: every wavefront takes six cells at a
+// time (ten lanes per cell) and runs on its own: the x-pass results cross lanes through a
+// wave-private LDS tile, and the loads of the next six cells are in flight while the
+// current ones are evaluated.
 // REG: the cells carry the interior weights, which reach the multiply-adds as scalar
-// operands from constant memory; otherwise each lane loads its cell's weights.
+// operands from constant memory; otherwise the ten lanes of a cell stage its column
+// weights, then its row weights, in the wave-private LDS array `wl`.
 template <bool REG>
-__global__ void __launch_bounds__(256)
-k_cell_filter(CellFilterArgs a) {
-    __shared__ FilterShared sh;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+__device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShared& sh, int seg, int wave_id,
+                                             int n_waves, int lane) {
+    const int wv = threadIdx.x >> 6;
     const int cs = lane / 10, r = lane - cs * 10;
     const bool lane_ok = cs < KF_CELLS_PER_WAVE;
     const int slot = wv * KF_CELLS_PER_WAVE + (lane_ok ? cs : 0);
     const int H = a.H, W = a.W;
-    const int seg = blockIdx.x % KF_NSEG;
-    const int wave_id = (blockIdx.x / KF_NSEG) * 4 + wv;       // within the segment
-    const int n_waves = (gridDim.x / KF_NSEG) * 4;             // the grid is a multiple of KF_NSEG
     const int n = min((REG ? a.n_reg : a.n_edge)[seg], a.seg_cap);
     const int32_t* list = a.cells + (size_t)seg * a.seg_cap;
-    if (tid == 0) sh.n_cand = 0;
-    __syncthreads();
+    float* wl = &sh.wts[slot][0];
 
     const int stride = n_waves * KF_CELLS_PER_WAVE;
     int base = wave_id * KF_CELLS_PER_WAVE;  // first cell of this wavefront's current six
+    if (base >= n) return;
     CellWork cur, nxt;
     load_cell<REG>(a, load_entry(list, n, base + cs, lane_ok, REG, a.seg_cap), r, cur);
     int e_next = load_entry(list, n, base + stride + cs, lane_ok, REG, a.seg_cap);
     while (base < n) {
-        load_cell<REG>(a, e_next, r, nxt);
-        e_next = load_entry(list, n, base + 2 * stride + cs, lane_ok, REG, a.seg_cap);
+        if (REG) {  // the few border cells go without the look-ahead, which costs registers
+            load_cell<REG>(a, e_next, r, nxt);
+            e_next = load_entry(list, n, base + 2 * stride + cs, lane_ok, REG, a.seg_cap);
+        }
         const bool act = cur.plane >= 0;
+        if (!REG) {
+            if (act && r < 9) {
+                const float4* kq = (const float4*)(a.cx + (size_t)cur.x * 72);
+                ((float4*)wl)[2 * r] = kq[2 * r];
+                ((float4*)wl)[2 * r + 1] = kq[2 * r + 1];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         // x pass: lane r < 9 owns source row y-4+r and forms the ten column sums
         if (act && r < 9) {
-            float k[72];
-            if (!REG) {
-                const float4* kq = (const float4*)(a.cx + (size_t)cur.x * 72);
-#pragma unroll
-                for (int q = 0; q < 18; ++q) {
-                    const float4 t = kq[q];
-                    k[4 * q] = t.x;
-                    k[4 * q + 1] = t.y;
-                    k[4 * q + 2] = t.z;
-                    k[4 * q + 3] = t.w;
-                }
-            }
             float* out = &sh.tile[slot][r][0];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -522,15 +517,24 @@ k_cell_filter(CellFilterArgs a) {
 #pragma unroll
                 for (int i = 5 * half; i < 5 * half + 5; ++i) {
                     const int p0 = i == 0 ? 0 : (i == 9 ? 2 : 1);
-                    float s = (REG ? kp[7 * i] : k[7 * i]) * cur.v[p0];
+                    if (!REG) asm volatile("" ::: "memory");  // keeps the weight reads of later sums out of registers
+                    float s = (REG ? kp[7 * i] : wl[7 * i]) * cur.v[p0];
 #pragma unroll
-                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * i + p] : k[7 * i + p], cur.v[p0 + p], s);
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * i + p] : wl[7 * i + p], cur.v[p0 + p], s);
                     out[i] = s;
                 }
             }
         }
-        // the tile is private to this wavefront, whose LDS accesses complete in order
+        // the tile and the weights are private to this wavefront, whose LDS accesses complete in order
         __builtin_amdgcn_wave_barrier();
+        if (!REG) {
+            if (act && r < 9) {
+                const float4* kq = (const float4*)(a.cy + (size_t)cur.y * 72);
+                ((float4*)wl)[2 * r] = kq[2 * r];
+                ((float4*)wl)[2 * r + 1] = kq[2 * r + 1];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         // y pass: lane r owns output column 8x-1+r and forms its ten row sums
         float S[10];
 #pragma unroll
@@ -539,27 +543,16 @@ k_cell_filter(CellFilterArgs a) {
             float t[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) t[q] = sh.tile[slot][q][r];
-            float k[72];
-            if (!REG) {
-                const float4* kq = (const float4*)(a.cy + (size_t)cur.y * 72);
-#pragma unroll
-                for (int q = 0; q < 18; ++q) {
-                    const float4 u = kq[q];
-                    k[4 * q] = u.x;
-                    k[4 * q + 1] = u.y;
-                    k[4 * q + 2] = u.z;
-                    k[4 * q + 3] = u.w;
-                }
-            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const ConstF* kp = fresh_pointer(c_kf_interior);
 #pragma unroll
                 for (int j = 5 * half; j < 5 * half + 5; ++j) {
                     const int p0 = j == 0 ? 0 : (j == 9 ? 2 : 1);
-                    float s = (REG ? kp[7 * j] : k[7 * j]) * t[p0];
+                    if (!REG) asm volatile("" ::: "memory");
+                    float s = (REG ? kp[7 * j] : wl[7 * j]) * t[p0];
 #pragma unroll
-                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * j + p] : k[7 * j + p], t[p0 + p], s);
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * j + p] : wl[7 * j + p], t[p0 + p], s);
                     S[j] = s;
                 }
             }
@@ -593,9 +586,29 @@ k_cell_filter(CellFilterArgs a) {
                 }
             }
         }
-        cur = nxt;
+        if (REG)
+            cur = nxt;
+        else
+            load_cell<REG>(a, load_entry(list, n, base + stride + cs, lane_ok, REG, a.seg_cap), r, cur);
         base += stride;
     }
+}
+
+// Workgroups of segment s = blockIdx.x % KF_NSEG share that segment's cells: first the
+// ones with interior weights, then the border ones (taken from the last wavefront of the
+// segment backwards, so that they fall to wavefronts with the fewest interior cells).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_cell_filter(CellFilterArgs a) {
+    __shared__ FilterShared sh;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int seg = blockIdx.x % KF_NSEG;
+    const int wave_id = (blockIdx.x / KF_NSEG) * 4 + wv;       // within the segment
+    const int n_waves = (gridDim.x / KF_NSEG) * 4;             // the grid is a multiple of KF_NSEG
+    if (tid == 0) sh.n_cand = 0;
+    __syncthreads();
+    filter_cells<true>(a, sh, seg, wave_id, n_waves, lane);
+    filter_cells<false>(a, sh, seg, n_waves - 1 - wave_id, n_waves, lane);
     // staged candidates -> this segment of the global list; entries beyond its capacity
     // mark their plane as overflowing instead (the exact kernel then redoes it)
     __syncthreads();
@@ -823,11 +836,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     if (fblocks > 2048) fblocks = 2048;
     fblocks = (fblocks + KF_NSEG - 1) / KF_NSEG * KF_NSEG;  // whole workgroups per segment
     pd_prof_begin(ctx, PD_STAGE_FILTER);
-    hipLaunchKernelGGL(k_cell_filter<true>, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, f);
-    pd_prof_end(ctx);
-    pd_prof_begin(ctx, PD_STAGE_FILTER_BORDER);
-    hipLaunchKernelGGL(k_cell_filter<false>, dim3((unsigned)((fblocks / 4 + KF_NSEG - 1) / KF_NSEG * KF_NSEG)), dim3(256), 0,
-                       ctx->stream, f);
+    hipLaunchKernelGGL(k_cell_filter, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, f);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
 

@@ -39,7 +39,7 @@ for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0) * 1024.0, write.get(k, 0.0) * 1024.0
     out['kernels'][k] = {'fetch_raw': f, 'fetch_corrected': 2.0 * f, 'write': w, 'hbm_bytes': 2.0 * f + w}
 for k, v in out['kernels'].items():
-    if 'k_cell_filter<true>' in k:
+    if 'k_cell_filter' in k:
         out['roofline_kernel'] = k
         out['roofline_kernel_hbm_bytes_per_launch'] = v['hbm_bytes']
 with open(os.path.join(DST, 'pmc_%s.json' % workload), 'w') as fh:
