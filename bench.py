@@ -40,24 +40,43 @@ def main():
     ap.add_argument('--cpu-images', type=int, default=12, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--people', type=int, default=0, help='experiments: fixed people per image')
-    ap.add_argument('--contexts', type=int, default=3, help='decode contexts (HIP streams) per GPU, used round-robin')
+    ap.add_argument('--contexts', type=int, default=0,
+                    help='decode contexts (HIP streams) per GPU, used round-robin (0: 4 on one GPU, 3 per rank under torch.distributed)')
+    ap.add_argument('--hw-queues', type=int, default=-1,
+                    help='GPU_MAX_HW_QUEUES for this process when the environment asks for fewer '
+                         '(0: leave it; -1: 8 on one GPU, left alone under torch.distributed)')
     args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    # PD_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL gather of the skeleton buffers)
+    # with a single rank, which is how that path is rehearsed on a one-GPU box
+    use_dist = world > 1 or os.environ.get('PD_BENCH_FORCE_DIST') == '1'
+    if args.contexts <= 0:
+        args.contexts = 3 if use_dist else 4
+    if args.hw_queues < 0:
+        # measured: the eager launches of the RCCL path lose throughput with more queues
+        args.hw_queues = 0 if use_dist else 8
 
+    # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default);
+    # streams that share a queue run one behind the other.  Every decode context needs a
+    # queue of its own next to the one torch uses, so raise the count before HIP starts
+    # (replayed launch graphs: four contexts on eight queues decode 12 % more than three on four).
+    try:
+        have_q = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    except ValueError:
+        have_q = 4
+    if args.hw_queues > have_q:
+        os.environ['GPU_MAX_HW_QUEUES'] = str(args.hw_queues)
     import torch
     import torch.distributed as dist
     from poseestimation_amd import _ffi, sharding, synth
     from poseestimation_amd.predict_decode import DecodeEngine, Results
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
-    # PD_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL gather of the skeleton buffers)
-    # with a single rank, which is how that path is rehearsed on a one-GPU box
-    use_dist = world > 1 or os.environ.get('PD_BENCH_FORCE_DIST') == '1'
     if use_dist:
         # RCCL writes a version banner to stdout when its first communicator comes up; stdout
         # carries the JSON line only, so the banner is sent to stderr
@@ -103,15 +122,17 @@ def main():
     GATHER_DEPTH = 2   # decodes per context between two gathers
     gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap, depth=GATHER_DEPTH) if use_dist else None
 
-    def run(nsteps):
+    def run(nsteps, pool=None):
         """nsteps steps = nsteps batches decoded and their skeletons brought to the host
         (N = 1: the packed results of the batch; N > 1: every rank's peaks and person
         rows gathered to rank 0 over RCCL)."""
         n, last = len(engs), None
         if gather is None:
+            pool = pool or engs
+            n = len(pool)
             pending = []
             for i in range(nsteps):
-                e = engs[i % n]
+                e = pool[i % n]
                 if len(pending) == n:
                     last = pending.pop(0).ctx.fetch()   # waits for that stream; results now on the host
                 e.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
@@ -174,6 +195,13 @@ def main():
         v = e.ctx.profile_read()[ROOF_STAGE]
         roof_ms += v[0]
         roof_n += v[1]
+    # the same event pair with one context decoding alone: the kernel's own duration, which is
+    # what a kernel trace (rocprofv3 serialises the kernels of all streams) reports; in the
+    # timed region the kernel shares the chip with the kernels of the other contexts' decodes
+    alone_ms, alone_n = 0.0, 0
+    if gather is None:
+        run(min(100, args.steps), pool=engs[:1])
+        alone_ms, alone_n = engs[0].ctx.profile_read()[ROOF_STAGE]
     prof = {}
     stage_steps = max(10, min(50, args.steps))
     for e in engs:
@@ -227,16 +255,26 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': desc, 'batch_per_gpu': B, 'mode': args.mode,
+                       'contexts_per_gpu': len(engs), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
                        'people_per_image': list(people) if isinstance(people, tuple) else people,
                        'outputs': 'packed skeleton lists copied to the host every step' if gather is None else
                                   'peaks and person rows of every rank gathered to rank 0 (RCCL) and copied to its host every step'},
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': sm_n,
-                         'algorithmic_bytes_per_launch': alg_bytes},
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'measured': 'HIP event pair around the kernel in every step of the timed region, '
+                                     '%d decodes in flight on the chip' % len(engs)},
             'job_hbm_frac_per_gpu': (value / world) * job_bytes / 1e9 / HBM_PEAK_GBS,
             'stage_ms_per_launch_untimed_pass': {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
+        if alone_n and kname == 'k_cell_filter':
+            a_s = alone_ms / alone_n * 1e-3
+            out['roofline']['one_context'] = {
+                'avg_launch_ms': a_s * 1e3, 'launches': alone_n, 'achieved': alg_bytes / a_s / 1e9,
+                'frac': alg_bytes / a_s / 1e9 / HBM_PEAK_GBS,
+                'measured': 'same event pair, one context decoding alone after the timed region '
+                            '(comparable with a kernel trace, which serialises kernels)'}
         res0 = last if gather is None else sharding.SkeletonGather.results(last)[0]
         out['persons_last_step'] = int(res0['person_count'].sum())
         out['filter_stats_last_step'] = eng.ctx.filter_stats()

@@ -495,7 +495,7 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
     load_cell<REG>(a, load_entry(list, n, base + cs, lane_ok, REG, a.seg_cap), r, cur);
     int e_next = load_entry(list, n, base + stride + cs, lane_ok, REG, a.seg_cap);
     while (base < n) {
-        if (REG) {  // the few border cells go without the look-ahead, which costs registers
+        if (REG) {  // the few border cells go without the look-ahead
             load_cell<REG>(a, e_next, r, nxt);
             e_next = load_entry(list, n, base + 2 * stride + cs, lane_ok, REG, a.seg_cap);
         }
@@ -597,7 +597,7 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
 // Workgroups of segment s = blockIdx.x % KF_NSEG share that segment's cells: first the
 // ones with interior weights, then the border ones (taken from the last wavefront of the
 // segment backwards, so that they fall to wavefronts with the fewest interior cells).
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(256)
 k_cell_filter(CellFilterArgs a) {
     __shared__ FilterShared sh;
     const int tid = threadIdx.x;
@@ -833,7 +833,9 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     pd_prof_end(ctx);
     // the list lengths are only known on the device: fixed grids stride over them
     size_t fblocks = (n_cells_max / 8 + KF_CELLS_PER_BLOCK - 1) / KF_CELLS_PER_BLOCK;
-    if (fblocks > 2048) fblocks = 2048;
+    // four workgroups per CU: with more, the kernel holds every wave slot of the chip and the
+    // kernels of the other decode contexts queue behind it (3 % fewer images/s at 2048)
+    if (fblocks > 1024) fblocks = 1024;
     fblocks = (fblocks + KF_NSEG - 1) / KF_NSEG * KF_NSEG;  // whole workgroups per segment
     pd_prof_begin(ctx, PD_STAGE_FILTER);
     hipLaunchKernelGGL(k_cell_filter, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, f);

@@ -10,6 +10,9 @@ heat, paf = synth.batch(B, H, W, (1, 8), seed0=0, paf_order='xy')
 dh, dp = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
 engs = [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode='D', max_peaks_per_part=128, max_persons=128,
                      max_pairs_per_image=40000) for _ in range(NC)]
+if len(sys.argv) > 2:      # event pair around one stage, as bench.py's timed region has it
+    for e in engs:
+        e.ctx.profile(stages=[sys.argv[2]])
 def run(n, tq, tf):
     pend = []
     for i in range(n):

@@ -14,8 +14,13 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r1'
 workload = 'b64_368'
 
 
+def newest(pattern):
+    # gpurun merges into gpurun_out/ without removing the files of earlier calls
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def counters(kind):
-    f = glob.glob(os.path.join(SRC, kind, '*', '*counter_collection.csv'))[0]
+    f = newest(os.path.join(SRC, kind, '*', '*counter_collection.csv'))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[r['Kernel_Name']].append(float(r['Counter_Value']))
@@ -24,7 +29,7 @@ def counters(kind):
 
 
 os.makedirs(DST, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(SRC, 'trace', '*', '*kernel_stats.csv'))[0],
+shutil.copy(newest(os.path.join(SRC, 'trace', '*', '*kernel_stats.csv')),
             os.path.join(DST, '%s_kernel_stats.csv' % tag))
 shutil.copy(os.path.join(SRC, 'bench.json'), os.path.join(DST, '%s_bench.json' % tag))
 shutil.copy(os.path.join(SRC, 'trace_bench.json'), os.path.join(DST, '%s_bench_under_rocprof.json' % tag))
