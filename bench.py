@@ -42,6 +42,11 @@ def main():
     ap.add_argument('--people', type=int, default=0, help='experiments: fixed people per image')
     ap.add_argument('--contexts', type=int, default=0,
                     help='decode contexts (HIP streams) per GPU, used round-robin (0: 4 on one GPU, 3 per rank under torch.distributed)')
+    ap.add_argument('--pipeline', default='fetch', choices=['fetch', 'rounds'],
+                    help='N = 1 only.  fetch: every decode replays its launch graph and copies its full packed '
+                         'results (with the connection lists) to the host; rounds: the N > 1 pipeline with a '
+                         'plain device-to-host copy in place of the RCCL gather (peaks + person rows per round '
+                         'of decodes, eager launches from the contexts\' launcher threads)')
     ap.add_argument('--hw-queues', type=int, default=-1,
                     help='GPU_MAX_HW_QUEUES for this process when the environment asks for fewer '
                          '(0: leave it; -1: 8 on one GPU, left alone under torch.distributed)')
@@ -50,11 +55,13 @@ def main():
     # PD_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL gather of the skeleton buffers)
     # with a single rank, which is how that path is rehearsed on a one-GPU box
     use_dist = world > 1 or os.environ.get('PD_BENCH_FORCE_DIST') == '1'
+    rounds = use_dist or args.pipeline == 'rounds'
     if args.contexts <= 0:
-        args.contexts = 3 if use_dist else 4
+        args.contexts = 4
     if args.hw_queues < 0:
-        # measured: the eager launches of the RCCL path lose throughput with more queues
-        args.hw_queues = 0 if use_dist else 8
+        # measured: replayed graphs want a queue per context (4 contexts: 8 queues), the eager
+        # launches of the round pipeline lose throughput with more than the default 4
+        args.hw_queues = 0 if rounds else 8
 
     # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default);
     # streams that share a queue run one behind the other.  Every decode context needs a
@@ -120,13 +127,21 @@ def main():
     # (contexts that are given a skeleton buffer launch eagerly: graph replay next to a live
     # process group faulted on this stack, see pd_set_skeleton_buffer)
     GATHER_DEPTH = 2   # decodes per context between two gathers
-    gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap, depth=GATHER_DEPTH) if use_dist else None
+    gather = gather1 = None
+    if rounds:
+        gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap, depth=GATHER_DEPTH, local=not use_dist)
+        gather1 = sharding.SkeletonGather([engs[0].ctx], gather_cap, depth=GATHER_DEPTH, local=True)
+        for e in engs:      # everything a rank produces leaves through the gather
+            e.ctx.set_host_results(False)
+
+    host_t = [0.0, 0.0, 0.0, 0.0, 0]   # finish, submit, flush, start, rounds
 
     def run(nsteps, pool=None):
         """nsteps steps = nsteps batches decoded and their skeletons brought to the host
         (N = 1: the packed results of the batch; N > 1: every rank's peaks and person
         rows gathered to rank 0 over RCCL)."""
         n, last = len(engs), None
+        pool_arg = pool
         if gather is None:
             pool = pool or engs
             n = len(pool)
@@ -142,27 +157,41 @@ def main():
             return last
         # rounds of GATHER_DEPTH decodes per context; the gather of round r (set r % 2 of the
         # send buffers) is in flight while round r + 1 decodes; the host never waits for a decode
+        g, pool = gather, engs
+        if pool_arg is not None:
+            g, pool = gather1, pool_arg
+        n = len(pool)
         last, r, done = None, 0, 0
         pending = [False, False]
         while done < nsteps:
             s = r % 2
+            ta = time.perf_counter()
             if pending[s]:
-                rows = gather.finish(s)
+                rows = g.finish(s)
                 last = rows if rows is not None else last
+            tb = time.perf_counter()
             k = min(n * GATHER_DEPTH, nsteps - done)
             # the contexts' launcher threads issue the (eager) kernel launches in parallel
             for j in range(k):
-                engs[j % n].ctx.submit(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, H, W, 0.1, 0.05,
-                                       gather.slice_ptr(s, j), gather.capacity)
-            for e in engs:
+                pool[j % n].ctx.submit(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, H, W, 0.1, 0.05,
+                                       g.slice_ptr(s, j), g.capacity)
+            tc = time.perf_counter()
+            for e in pool:
                 e.ctx.flush()
-            gather.start(s)
+            td = time.perf_counter()
+            g.start(s)
+            te = time.perf_counter()
+            host_t[0] += tb - ta
+            host_t[1] += tc - tb
+            host_t[2] += td - tc
+            host_t[3] += te - td
+            host_t[4] += 1
             pending[s] = True
             done += k
             r += 1
         for s in (r % 2, (r + 1) % 2):
             if pending[s]:
-                rows = gather.finish(s)
+                rows = g.finish(s)
                 last = rows if rows is not None else last
         return last
 
@@ -186,10 +215,14 @@ def main():
     for e in engs:
         e.ctx.profile_read()
     barrier()
+    host_t[:] = [0.0, 0.0, 0.0, 0.0, 0]
     t0 = time.perf_counter()
     last = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get('PD_BENCH_TIMERS') == '1' and host_t[4]:
+        sys.stderr.write('host us per round: finish %.1f submit %.1f flush %.1f start %.1f (rounds %d)\n'
+                         % tuple([x / host_t[4] * 1e6 for x in host_t[:4]] + [host_t[4]]))
     roof_ms, roof_n = 0.0, 0
     for e in engs:
         v = e.ctx.profile_read()[ROOF_STAGE]
@@ -199,7 +232,7 @@ def main():
     # what a kernel trace (rocprofv3 serialises the kernels of all streams) reports; in the
     # timed region the kernel shares the chip with the kernels of the other contexts' decodes
     alone_ms, alone_n = 0.0, 0
-    if gather is None:
+    if not use_dist:
         run(min(100, args.steps), pool=engs[:1])
         alone_ms, alone_n = engs[0].ctx.profile_read()[ROOF_STAGE]
     prof = {}
@@ -257,8 +290,12 @@ def main():
             'config': {'workload': desc, 'batch_per_gpu': B, 'mode': args.mode,
                        'contexts_per_gpu': len(engs), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
                        'people_per_image': list(people) if isinstance(people, tuple) else people,
-                       'outputs': 'packed skeleton lists copied to the host every step' if gather is None else
-                                  'peaks and person rows of every rank gathered to rank 0 (RCCL) and copied to its host every step'},
+                       'outputs': 'full packed results (peaks, connection lists, person rows) copied to the host every step'
+                                  if gather is None else
+                                  'peaks and person rows copied to the host once per round of %d decodes' % gather.n
+                                  if not use_dist else
+                                  'peaks and person rows of every rank gathered to rank 0 (RCCL) and copied to its host, '
+                                  'once per round of %d decodes per rank' % gather.n},
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': sm_n,
@@ -279,7 +316,7 @@ def main():
         out['persons_last_step'] = int(res0['person_count'].sum())
         out['filter_stats_last_step'] = eng.ctx.filter_stats()
 
-        if gather is None and not args.no_cpu:
+        if not use_dist and not args.no_cpu:
             from oracle import decode_ref as ref
             ncpu = min(args.cpu_images, B)
             r = Results(res0, eng.mode)

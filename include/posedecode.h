@@ -232,6 +232,15 @@ int pd_flush(pd_ctx* ctx);
  * reference: the reference is single-process. */
 int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t capacity);
 
+/* enable = 0: while a skeleton buffer is set, a pack writes that buffer only -- no packed
+ * result buffer, no copy to the host mirror -- and pd_sync_totals (with totals; with
+ * NULL it only waits for the stream) / pd_fetch / pd_results_host / pd_packed_device report
+ * PD_E_STATE; per-image status and the first bad image are in the skeleton buffer's
+ * header and tables.  For ranks of a multi-GPU job
+ * whose results leave through the gather.  On by default; no effect without a skeleton
+ * buffer.  No counterpart in the reference. */
+int pd_set_host_results(pd_ctx* ctx, int enable);
+
 /* Counters of the last peak stage that went through the candidate filter
  * (PD_IMPL_FAST on network-resolution sources): out[0] candidates handed to the exact
  * verification, out[1] / out[2] active 8 x 8 pixel cells with interior / border

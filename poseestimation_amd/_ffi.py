@@ -22,7 +22,7 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay', 'pd_set_host_results']
 
 STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells', 'filter_border']
 
@@ -128,6 +128,7 @@ def lib():
     L.pd_submit.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, dbl, dbl, vp, C.c_uint64]
     L.pd_flush.argtypes = [vp]
     L.pd_set_graph_replay.argtypes = [vp, i32]
+    L.pd_set_host_results.argtypes = [vp, i32]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -333,6 +334,10 @@ class Context:
     def set_skeleton_buffer(self, device_ptr, capacity):
         """Device buffer that receives peaks + person rows (no connections) with every pack."""
         self.check(self.L.pd_set_skeleton_buffer(self._h, device_ptr, capacity))
+
+    def set_host_results(self, enable):
+        """False: with a skeleton buffer set, decodes write that buffer only (nothing to fetch)."""
+        self.check(self.L.pd_set_host_results(self._h, 1 if enable else 0))
 
     def submit(self, heat_ptr, paf_ptr, B, h, w, H, W, thre1, thre2, skeleton_ptr=None, skeleton_capacity=0):
         """Queue a decode of device-resident inputs for the context's launcher thread."""

@@ -60,6 +60,7 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     ctx->mode = PD_MODE_P;
     ctx->impl = PD_IMPL_FAST;
     ctx->use_graph = getenv("PD_NO_GRAPH") ? 0 : 1;
+    ctx->host_results = 1;
 #define CR(call)                                                                     \
     do {                                                                             \
         int rc_ = (call);                                                            \
@@ -476,6 +477,16 @@ extern "C" int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t ca
     return PD_OK;
 }
 
+extern "C" int pd_set_host_results(pd_ctx* ctx, int enable) {
+    PD_CHECK_CTX(ctx);
+    ctx->host_results = enable ? 1 : 0;
+    return PD_OK;
+}
+
+// With a skeleton buffer set and host results switched off, a pack writes the skeleton
+// buffer only.
+static inline bool skeleton_only(const pd_ctx* ctx) { return ctx->skel_dst != nullptr && !ctx->host_results; }
+
 extern "C" int pd_filter_stats(pd_ctx* ctx, int64_t* out) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
@@ -614,6 +625,11 @@ extern "C" int pd_pack(pd_ctx* ctx) {
     if (!ctx->have_peaks && !ctx->have_conns && !ctx->have_persons) PD_FAIL(ctx, PD_E_STATE, "pd_pack: nothing to pack");
     int rc = pd_launch_pack(ctx);
     if (rc != PD_OK) return rc;
+    if (skeleton_only(ctx)) {  // nothing for pd_fetch and its like: they report PD_E_STATE
+        ctx->res_have = 0;
+        ctx->packed = 0;
+        return PD_OK;
+    }
     // header, count tables and (speculatively) the head of the payload in one copy
     const ResLayout lay = pd_res_layout(ctx->B);
     size_t spec = lay.off_payload + 65536 + (size_t)ctx->B * 6144;
@@ -701,9 +717,11 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     key.impl = ctx->impl;
     key.prof = ctx->prof_on;
     key.skel = ctx->skel_dst;
+    key.host_results = ctx->host_results;
     if (ctx->graph_exec && memcmp(&key, &ctx->graph_key, sizeof(key)) == 0) {
         PD_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
-        ctx->have_peaks = ctx->have_conns = ctx->have_persons = ctx->packed = 1;
+        ctx->have_peaks = ctx->have_conns = ctx->have_persons = 1;
+        ctx->packed = skeleton_only(ctx) ? 0 : 1;
         ctx->res_have = ctx->graph_res_have;
         ctx->prof_n = ctx->graph_prof_n;
         return PD_OK;
@@ -886,6 +904,12 @@ extern "C" int pd_packed_device(pd_ctx* ctx, void** peaks, void** conns, void** 
 extern "C" int pd_sync_totals(pd_ctx* ctx, pd_totals* totals) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    if (!ctx->packed && !totals && skeleton_only(ctx)) {
+        // nothing was packed for the host: wait for the stream; the per-image status is in
+        // the skeleton buffer
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PD_OK;
+    }
     if (!ctx->packed) PD_FAIL(ctx, PD_E_STATE, "pd_sync_totals: call pd_pack (or a decode entry point) first");
     int rc = finish_results(ctx);
     if (rc != PD_OK) return rc;

@@ -94,6 +94,7 @@ struct GraphKey {
     double t1, t2;
     int mode, impl;
     uint32_t prof;
+    int host_results;
     const void* skel;
 };
 
@@ -194,6 +195,7 @@ struct pd_ctx {
     int have_peaks, have_conns, have_persons, packed;
     unsigned char* skel_dst;  // caller's device buffer for the skeleton copy of the results (or NULL)
     size_t skel_cap;
+    int host_results;         // 0: with a skeleton buffer set, results go there only (no host mirror)
     // ---- stage timing (pd_profile) ----
     uint32_t prof_on;               // bit s set: stage s is timed
     int prof_open;                  // a start event is waiting for its stop

@@ -590,7 +590,7 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.cap = 0;
     a.lay = pd_res_layout(ctx->B);
     pd_prof_begin(ctx, PD_STAGE_PACK);
-    hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
+    if (!ctx->skel_dst || ctx->host_results) hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
     if (ctx->skel_dst) {
         // the caller's device buffer gets the same layout without the connection lists
         a.res = ctx->skel_dst;

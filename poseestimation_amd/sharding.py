@@ -117,24 +117,31 @@ class SkeletonGather:
     uint8 array: rank-major, then in slice order.
     """
 
-    def __init__(self, contexts, capacity, group=None, dst=0, device=None, sets=2, depth=1):
+    def __init__(self, contexts, capacity, group=None, dst=0, device=None, sets=2, depth=1, local=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.group, self.dst, self.capacity = group, dst, int(capacity)
         self.contexts = list(contexts)
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-        self.on_gpu = dist.get_backend(group) == 'nccl'
+        # local: a single process without a process group; the "gather" is then the copy of
+        # the send set to pinned host memory, with the same rounds and the same result rows
+        self.local = bool(local)
+        if self.local:
+            self.world, self.rank, self.dst, self.on_gpu = 1, 0, 0, True
+        else:
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+            self.on_gpu = dist.get_backend(group) == 'nccl'
         dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
         n = self.n = len(self.contexts) * int(depth)   # slices per set
         row = n * self.capacity
         self.send = [torch.zeros(row, dtype=torch.uint8, device=dev) for _ in range(sets)]
         self.stage = None if self.on_gpu else [torch.zeros(row, dtype=torch.uint8) for _ in range(sets)]
         self.recv = self.host = None
-        if self.rank == dst:
+        if self.rank == self.dst:
             rdev = dev if self.on_gpu else torch.device('cpu')
-            self.recv = [torch.zeros(self.world * row, dtype=torch.uint8, device=rdev) for _ in range(sets)]
+            if not self.local:
+                self.recv = [torch.zeros(self.world * row, dtype=torch.uint8, device=rdev) for _ in range(sets)]
             if self.on_gpu:
                 self.host = [torch.zeros(self.world * row, dtype=torch.uint8).pin_memory() for _ in range(sets)]
         self.work = [None] * sets
@@ -143,6 +150,7 @@ class SkeletonGather:
             # the contexts' own HIP streams, as torch sees them
             self.streams = [torch.cuda.ExternalStream(int(c.stream), device=dev) for c in self.contexts]
             self.copy_stream = torch.cuda.Stream(device=dev)
+            self.done = [torch.cuda.Event() for _ in range(sets)]
 
     def slice_ptr(self, s, j):
         """Device address of slice ``j`` of set ``s`` (for ``Context.submit``)."""
@@ -153,6 +161,14 @@ class SkeletonGather:
 
     def start(self, s):
         src = self.send[s]
+        if self.local:
+            for st in self.streams:
+                self.copy_stream.wait_stream(st)   # the copy is ordered behind this round's decodes
+            with self.torch.cuda.stream(self.copy_stream):
+                self.host[s].copy_(src, non_blocking=True)
+                self.done[s].record()
+            self.work[s] = True
+            return
         if self.on_gpu:
             cur = self.torch.cuda.current_stream()
             for st in self.streams:
@@ -164,6 +180,15 @@ class SkeletonGather:
         if self.rank == self.dst:
             gl = list(self.recv[s].view(self.world, -1).unbind(0))
         self.work[s] = self.dist.gather(src, gather_list=gl, dst=self.dst, group=self.group, async_op=True)
+        if self.on_gpu:
+            # wait() orders a stream behind the collective without blocking the host; the copy to
+            # pinned memory is queued right away on a stream of its own, so that finish() finds
+            # it done (or under way) and waits for nothing else
+            with self.torch.cuda.stream(self.copy_stream):
+                self.work[s].wait()
+                if self.rank == self.dst:
+                    self.host[s].copy_(self.recv[s], non_blocking=True)
+                self.done[s].record()
 
     def finish(self, s):
         work, self.work[s] = self.work[s], None
@@ -171,13 +196,7 @@ class SkeletonGather:
             return None
         out = None
         if self.on_gpu:
-            # wait() orders a stream behind the collective; a stream of its own keeps the host
-            # wait below from also waiting for the decodes queued since
-            with self.torch.cuda.stream(self.copy_stream):
-                work.wait()
-                if self.rank == self.dst:
-                    self.host[s].copy_(self.recv[s], non_blocking=True)
-            self.copy_stream.synchronize()
+            self.done[s].synchronize()   # this set's copy only: the next round's is queued behind it
             if self.rank == self.dst:
                 out = self.host[s].numpy()
         else:

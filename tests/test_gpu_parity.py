@@ -340,6 +340,34 @@ def test_skeleton_buffer_holds_peaks_and_persons(pdec):
     eng.close()
 
 
+def test_skeleton_only_decode_has_nothing_to_fetch(pdec):
+    """pd_set_host_results(0): the decode writes the skeleton buffer (same bytes as with the
+    host results on) and nothing else; fetching then is a state error, not stale data."""
+    import torch
+    from poseestimation_amd import synth
+    H = W = 184
+    heat, paf = synth.batch(4, H, W, (1, 4), seed0=75, paf_order='xy')
+    dh, dp = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    eng = pdec.DecodeEngine(max_batch=4, max_h=H, max_w=W, mode='D')
+    both = torch.zeros(1 << 16, dtype=torch.uint8, device='cuda')
+    only = torch.zeros(1 << 16, dtype=torch.uint8, device='cuda')
+    eng.ctx.set_skeleton_buffer(both.data_ptr(), both.numel())
+    eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), 4, 23, 23, (H, W))
+    assert eng.fetch().packed['person_count'].sum() > 0
+    eng.ctx.set_host_results(False)
+    eng.ctx.set_skeleton_buffer(only.data_ptr(), only.numel())
+    eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), 4, 23, 23, (H, W))
+    eng.ctx.sync()
+    assert torch.equal(both, only)
+    with pytest.raises(RuntimeError):
+        eng.ctx.fetch()
+    # without a skeleton buffer the switch has no effect
+    eng.ctx.set_skeleton_buffer(None, 0)
+    eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), 4, 23, 23, (H, W))
+    assert eng.fetch().packed['person_count'].sum() > 0
+    eng.close()
+
+
 def test_submit_launches_from_the_context_thread(pdec):
     """pd_submit / pd_flush: decodes queued for the context's launcher thread write the same
     skeleton buffers as direct calls, in order, and errors surface at the flush."""
@@ -365,6 +393,47 @@ def test_submit_launches_from_the_context_thread(pdec):
     with pytest.raises(ValueError):
         eng.ctx.flush()
     eng.close()
+
+
+def test_rounds_without_a_process_group(pdec):
+    """SkeletonGather(local=True): the round pipeline of a multi-GPU job in one process, the
+    gather replaced by the copy to pinned memory; two contexts, two decodes each per round,
+    skeleton-only contexts.  Every decode of every round arrives, in slice order."""
+    import torch
+    from poseestimation_amd import sharding, synth
+    H = W = 184
+    batches = [synth.batch(3, H, W, (1, 3), seed0=s, paf_order='xy') for s in (100, 110, 120)]
+    want = [pdec.DecodeEngine(3, H, W, mode='D').decode_batch(h, p).packed for h, p in batches]
+    dev = [(torch.from_numpy(h).cuda(), torch.from_numpy(p).cuda()) for h, p in batches]
+    engs = [pdec.DecodeEngine(max_batch=3, max_h=H, max_w=W, mode='D') for _ in range(2)]
+    for e in engs:
+        e.ctx.set_host_results(False)
+    g = sharding.SkeletonGather([e.ctx for e in engs], 1 << 16, depth=2, local=True)
+    fed, seen = [], []
+    pending = [None, None]
+    for r in range(5):
+        s = r % 2
+        if pending[s] is not None:
+            seen.append((pending[s], sharding.SkeletonGather.results(g.finish(s))))
+        ids = [(r + j) % 3 for j in range(4)]
+        for j, i in enumerate(ids):
+            dh, dp = dev[i]
+            engs[j % 2].ctx.submit(dh.data_ptr(), dp.data_ptr(), 3, 23, 23, H, W, 0.1, 0.05, g.slice_ptr(s, j), g.capacity)
+        for e in engs:
+            e.ctx.flush()
+        g.start(s)
+        pending[s] = ids
+        fed.append(ids)
+    for s in (1, 0):
+        seen.append((pending[s], sharding.SkeletonGather.results(g.finish(s))))
+    assert len(seen) == 5
+    for ids, res in seen:
+        assert len(res) == 4
+        for j, i in enumerate(ids):
+            for key in ('part_count', 'person_count', 'status', 'peaks', 'persons'):
+                assert np.array_equal(res[j][key], want[i][key]), (ids, j, key)
+    for e in engs:
+        e.close()
 
 
 @pytest.mark.parametrize('caps', [dict(max_peaks_per_part=2), dict(max_pairs_per_image=20), dict(max_persons=1)])
