@@ -86,6 +86,10 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     // counters that start every decode at zero share one allocation and one memset
     ctx->zero_bytes = (2 * B * PD_N_PARTS + 96 + 3 * B) * sizeof(int32_t);
     CR(dev_alloc(ctx, (void**)&ctx->zero_block, ctx->zero_bytes));
+    CRH(hipMemset(ctx->zero_block, 0, ctx->zero_bytes));
+    ctx->zero_clean = 1;
+    CR(dev_alloc(ctx, (void**)&ctx->fstats, 4 * sizeof(int64_t)));
+    CRH(hipMemset(ctx->fstats, 0, 4 * sizeof(int64_t)));
     ctx->raw_count = ctx->zero_block;
     ctx->cand_count = ctx->raw_count + B * PD_N_PARTS;                 // [B][18] + 3 x 32 list counters
     ctx->absmax = (float*)(ctx->cand_count + B * PD_N_PARTS + 96);     // [B] max |v|, then [B] (thr_lo, e2)
@@ -150,7 +154,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
-                    ctx->heat_planar, ctx->paf_pairs};
+                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (TableSlot& t : ctx->tabs) {
@@ -492,18 +496,9 @@ extern "C" int pd_filter_stats(pd_ctx* ctx, int64_t* out) {
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     if (!out) PD_FAIL(ctx, PD_E_INVALID, "pd_filter_stats: out is NULL");
     out[0] = out[1] = out[2] = out[3] = 0;
-    if (!ctx->cand_count || ctx->B < 1) return PD_OK;
-    const size_t planes = (size_t)ctx->B * PD_N_PARTS;
-    const int nseg = 32;  // segments per list (KF_NSEG of the filter)
-    std::vector<int32_t> host(planes + 3 * nseg);
+    if (!ctx->fstats) return PD_OK;
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PD_HIP(ctx, hipMemcpy(host.data(), ctx->cand_count, sizeof(int32_t) * host.size(), hipMemcpyDeviceToHost));
-    for (int i = 0; i < nseg; ++i) {
-        out[0] += host[planes + i];
-        out[1] += host[planes + nseg + i];
-        out[2] += host[planes + 2 * nseg + i];
-    }
-    for (size_t i = 0; i < planes; ++i) out[3] += host[i] > ctx->cand_cap;
+    PD_HIP(ctx, hipMemcpy(out, ctx->fstats, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return PD_OK;
 }
 
@@ -719,7 +714,10 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     key.skel = ctx->skel_dst;
     key.host_results = ctx->host_results;
     if (ctx->graph_exec && memcmp(&key, &ctx->graph_key, sizeof(key)) == 0) {
+        // the graph was recorded behind a decode that left the counters zero, so it holds no memset
+        if (!ctx->zero_clean) PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));
         PD_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+        ctx->zero_clean = 1;
         ctx->have_peaks = ctx->have_conns = ctx->have_persons = 1;
         ctx->packed = skeleton_only(ctx) ? 0 : 1;
         ctx->res_have = ctx->graph_res_have;

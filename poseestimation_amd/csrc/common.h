@@ -167,8 +167,10 @@ struct pd_ctx {
     size_t paf_pairs_cap;
     int cand_cap;                    // CK
     // ---- peaks ----
-    int32_t* zero_block; // raw_count | cand_count + list counters | absmax + slack: cleared by one memset per decode
+    int32_t* zero_block; // raw_count | cand_count + list counters | absmax + slack: zero at the start of every decode
     size_t zero_bytes;
+    int zero_clean;      // the block is zero (or a kernel that zeroes it is queued): pd_pack leaves it so
+    int64_t* fstats;     // what pd_filter_stats reports, summed up by k_sort_peaks before the counters go
     RawPeak* raw;        // [B][18][PK] unordered
     int32_t* raw_count;  // [B][18]
     int32_t *pk_y, *pk_x, *pk_id;  // [B][18][PK] sorted (y, x) ascending

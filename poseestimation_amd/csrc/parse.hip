@@ -431,6 +431,8 @@ struct PackArgs {
     unsigned char* res;  // result buffer: header | count tables | peaks | conns | persons
     unsigned long long cap;  // bytes behind res, 0 = large enough by construction
     ResLayout lay;
+    int32_t* zero;           // counters to clear for the next decode (or NULL)
+    int zero_words;
 };
 
 // One workgroup per image.  Every workgroup sums the item counts of all images itself
@@ -444,6 +446,9 @@ k_pack(PackArgs a) {
     __shared__ int s_pbase[PD_N_PARTS + 1], s_lbase[PD_N_LIMBS + 1];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    // every stage that reads the per-decode counters has run: leave them zero for the next decode
+    if (a.zero)
+        for (int i = b * 256 + tid; i < a.zero_words; i += gridDim.x * 256) a.zero[i] = 0;
     long long acc[6] = {0, 0, 0, 0, 0, 0};
     int bad = 0x7fffffff;
     for (int j = tid; j < a.B; j += 256) {
@@ -589,8 +594,13 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.res = ctx->res_dev;
     a.cap = 0;
     a.lay = pd_res_layout(ctx->B);
+    a.zero = ctx->zero_block;
+    a.zero_words = (int)(ctx->zero_bytes / sizeof(int32_t));
     pd_prof_begin(ctx, PD_STAGE_PACK);
-    if (!ctx->skel_dst || ctx->host_results) hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
+    if (!ctx->skel_dst || ctx->host_results) {
+        hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
+        a.zero = nullptr;
+    }
     if (ctx->skel_dst) {
         // the caller's device buffer gets the same layout without the connection lists
         a.res = ctx->skel_dst;
@@ -600,5 +610,6 @@ int pd_launch_pack(pd_ctx* ctx) {
     }
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
+    ctx->zero_clean = 1;
     return PD_OK;
 }

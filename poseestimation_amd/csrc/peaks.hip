@@ -13,14 +13,17 @@
 __global__ void __launch_bounds__(SORT_WAVES * 64)
 k_sort_peaks(const RawPeak* __restrict__ raw, const int32_t* __restrict__ raw_count, int PK, int W,
              int max_pairs, int32_t* pk_y, int32_t* pk_x, int32_t* pk_id, double* pk_score,
-             int32_t* part_count, int32_t* part_base, int32_t* pair_off, int32_t* status) {
+             int32_t* part_count, int32_t* part_base, int32_t* pair_off, int32_t* status,
+             const int32_t* __restrict__ cand_count, int n_planes, int cand_cap, int64_t* fstats) {
     __shared__ int32_t s_cnt[PD_N_PARTS];
     __shared__ int32_t s_base[PD_N_PARTS + 1];
     __shared__ int s_over;
+    __shared__ unsigned long long s_stat[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     if (tid == 0) s_over = 0;
+    if (tid < 4) s_stat[tid] = 0ull;
     __syncthreads();
     if (tid < PD_N_PARTS) {
         int n = raw_count[b * PD_N_PARTS + tid];
@@ -54,6 +57,15 @@ k_sort_peaks(const RawPeak* __restrict__ raw, const int32_t* __restrict__ raw_co
         status[b] = s_over ? PD_E_OVERFLOW : PD_OK;
     }
     __syncthreads();
+    if (b == 0) {
+        // what the candidate filter did, for pd_filter_stats: the counters themselves are
+        // cleared by the pack kernel.  Behind the per-plane counts sit 3 x 32 list counters
+        // (candidates, interior cells, border cells).
+        unsigned long long over = 0;
+        for (int i = tid; i < n_planes; i += SORT_WAVES * 64) over += cand_count[i] > cand_cap;
+        if (over) atomicAdd(&s_stat[3], over);
+        if (tid < 96) atomicAdd(&s_stat[tid >> 5], (unsigned long long)cand_count[n_planes + tid]);
+    }
     if (tid < PD_N_PARTS) part_count[b * PD_N_PARTS + tid] = s_cnt[tid];
     if (tid <= PD_N_PARTS) part_base[b * (PD_N_PARTS + 1) + tid] = s_base[tid];
     for (int p = wave; p < PD_N_PARTS; p += SORT_WAVES) {
@@ -88,13 +100,18 @@ k_sort_peaks(const RawPeak* __restrict__ raw, const int32_t* __restrict__ raw_co
             }
         }
     }
+    if (b == 0) {
+        __syncthreads();
+        if (tid < 4) fstats[tid] = (int64_t)s_stat[tid];
+    }
 }
 
 int pd_launch_sort_peaks(pd_ctx* ctx) {
     pd_prof_begin(ctx, PD_STAGE_SORT);
     hipLaunchKernelGGL(k_sort_peaks, dim3(ctx->B), dim3(SORT_WAVES * 64), 0, ctx->stream, ctx->raw, ctx->raw_count,
                        ctx->cfg.max_peaks_per_part, ctx->W, ctx->cfg.max_pairs_per_image, ctx->pk_y, ctx->pk_x,
-                       ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off, ctx->status);
+                       ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off, ctx->status,
+                       ctx->cand_count, ctx->B * PD_N_PARTS, ctx->cand_cap > 0 ? ctx->cand_cap : 0x7fffffff, ctx->fstats);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;

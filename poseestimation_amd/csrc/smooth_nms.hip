@@ -285,7 +285,10 @@ int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smo
 int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
     const int B = ctx->B, H = ctx->H, W = ctx->W;
     MapSource src = pd_heat_source(ctx);
-    PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));  // raw_count and the filter's counters
+    // raw_count and the filter's counters start at zero; the pack kernel of the previous
+    // decode has normally seen to that
+    if (!ctx->zero_clean) PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));
+    ctx->zero_clean = 0;
     const int f32mode = (ctx->src_kind == PD_SRC_FULLRES) ? ctx->heat_f32 : 0;
     // float32 data is thresholded in float32 (numpy compares a float32 array with a
     // Python float in float32)
