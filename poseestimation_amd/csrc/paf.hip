@@ -64,6 +64,39 @@ __device__ __forceinline__ void bicubic2_at(const float* __restrict__ img, int h
     *o1 = ((h1[0] * bc.x + h1[1] * bc.y) + h1[2] * bc.z) + h1[3] * bc.w;
 }
 
+// The same for the pair-planar copy (h, w, 2): the four horizontal taps of both channels
+// are 32 contiguous bytes, fetched with two 16-byte loads per row when no tap is clamped.
+struct __attribute__((aligned(8))) float4a8 {
+    float x, y, z, w;
+};
+
+__device__ __forceinline__ void bicubic2_planar(const float* __restrict__ img, int h, int w, int Y, int X,
+                                                const float4* __restrict__ up, float* o0, float* o1) {
+    const int x0 = pd_up8_ofs(X);
+    if (x0 < 0 || x0 + 3 > w - 1) {  // a clamped tap: the general form
+        bicubic2_at(img, h, w, 2, 0, Y, X, up, o0, o1);
+        return;
+    }
+    const int y0 = pd_up8_ofs(Y);
+    const float4 ac = up[pd_up8_phase(X)];
+    const float4 bc = up[pd_up8_phase(Y)];
+    float4a8 lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* row = img + ((size_t)pd_clampi(y0 + k, 0, h - 1) * w + x0) * 2;
+        lo[k] = *(const float4a8*)row;        // (c0, c1) of taps 0 and 1
+        hi[k] = *(const float4a8*)(row + 4);  // (c0, c1) of taps 2 and 3
+    }
+    float h0[4], h1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h0[k] = ((lo[k].x * ac.x + lo[k].z * ac.y) + hi[k].x * ac.z) + hi[k].z * ac.w;
+        h1[k] = ((lo[k].y * ac.x + lo[k].w * ac.y) + hi[k].y * ac.z) + hi[k].w * ac.w;
+    }
+    *o0 = ((h0[0] * bc.x + h0[1] * bc.y) + h0[2] * bc.z) + h0[3] * bc.w;
+    *o1 = ((h1[0] * bc.x + h1[1] * bc.y) + h1[2] * bc.z) + h1[3] * bc.w;
+}
+
 // What the ten sample lanes of a pair need, computed once per pair.
 struct PairGeo {
     double u0, u1;   // unit vector components paired with channels 2k and 2k+1
@@ -75,12 +108,130 @@ struct PairGeo {
 };
 
 #define PAIRS_PER_CHUNK 6   // pairs a wavefront takes at a time: 6 lanes x 1 pair, then 6 pairs x 10 samples
+#define PRE_PAIRS 128       // pairs a wavefront pre-tests (one lane each) before it scores the survivors
 
-// Every wavefront works on its own: lanes 0..5 first derive the geometry of six pairs,
-// then ten lanes per pair take one sample point each, and lane 0 of each group adds the
-// ten products in sample order.  The kernel is bound by the latency of the sample
+// Limb, peak indices and unit vector of candidate pair p of image b; false: the pair is
+// skipped (coincident peaks in mode P).
+__device__ __forceinline__ bool pair_geometry(const PairArgs& a, int b, int p, const int32_t* s_off,
+                                              const int32_t* s_cnt, PairGeo& g) {
+    int k = 0;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1)
+        if (k + d <= PD_N_LIMBS - 1 && s_off[k + d] <= p) k += d;
+    const int pa = pd_limb_from(k), pb = pd_limb_to(k);
+    const int nB = s_cnt[pb];
+    const int local = p - s_off[k];
+    const int ia = local / nB, ib = local - ia * nB;
+    const size_t oa = ((size_t)b * PD_N_PARTS + pa) * a.PK + ia;
+    const size_t ob = ((size_t)b * PD_N_PARTS + pb) * a.PK + ib;
+    g.ya = a.pk_y[oa];
+    g.xa = a.pk_x[oa];
+    g.yb = a.pk_y[ob];
+    g.xb = a.pk_x[ob];
+    const long long dy = (long long)g.yb - g.ya, dx = (long long)g.xb - g.xa;
+    const double d2 = (double)(dy * dy + dx * dx);
+    double norm = sqrt(d2);
+    bool skip = false;
+    if (a.mode == PD_MODE_P)
+        skip = d2 == 0.0;  // coincident peaks, utils/postprocess.py:112
+    else
+        norm = fmax(norm, 1e-5);  // predict.py:141
+    const double uy = (double)dy / norm, ux = (double)dx / norm;
+    if (a.mode == PD_MODE_P) {  // channel 2k pairs with dy, 2k+1 with dx
+        g.u0 = uy;
+        g.u1 = ux;
+    } else {                    // channel 2k pairs with dx, 2k+1 with dy
+        g.u0 = ux;
+        g.u1 = uy;
+    }
+    g.sy = (double)dy / 9.0;
+    g.sx = (double)dx / 9.0;
+    g.prior = fmin(0.5 * (double)a.src.H / norm - 1.0, 0.0);
+    g.k = skip ? -1 : k;
+    g.pad = 0;
+    return !skip;
+}
+
+// v0 * u0 + v1 * u1 at sample i of the pair (i = 9 is the second peak itself).
+__device__ __forceinline__ double pair_sample(const PairArgs& a, int b, const PairGeo& g, int i, const float4* s_up) {
+    const int H = a.src.H, W = a.src.W;
+    double py, px;
+    if (i == PD_MID - 1) {
+        py = (double)g.yb;
+        px = (double)g.xb;
+    } else {
+        py = (double)i * g.sy + (double)g.ya;
+        px = (double)i * g.sx + (double)g.xa;
+    }
+    int iy, ix;
+    if (a.mode == PD_MODE_P) {
+        iy = (int)py;
+        ix = (int)px;
+    } else {
+        iy = (int)rint(py);
+        ix = (int)rint(px);
+    }
+    iy = pd_clampi(iy, 0, H - 1);
+    ix = pd_clampi(ix, 0, W - 1);
+    double v0, v1;
+    if (a.src.kind == PD_SRC_LOWRES) {
+        float f0, f1;
+        if (a.pairs)
+            bicubic2_planar(a.pairs + ((size_t)b * PD_N_LIMBS + g.k) * a.src.h * a.src.w * 2, a.src.h, a.src.w, iy, ix,
+                            s_up, &f0, &f1);
+        else
+            bicubic2_at(a.src.lo + (size_t)b * a.src.h * a.src.w * a.src.C, a.src.h, a.src.w, a.src.C, 2 * g.k, iy, ix,
+                        s_up, &f0, &f1);
+        v0 = (double)f0;
+        v1 = (double)f1;
+    } else {
+        const size_t npx = (size_t)H * W;
+        const double* pl = a.src.full + ((size_t)b * a.src.Cfull + 2 * g.k) * npx + (size_t)iy * W + ix;
+        v0 = pl[0];
+        v1 = pl[npx];
+    }
+    return v0 * g.u0 + v1 * g.u1;
+}
+
+// Scores up to six pairs whose geometry (k < 0: nothing to do) and pair indices lie in
+// geo[0..5] / p6[0..5]: ten lanes per pair take one sample point each, and lane 0 of each
+// group adds the ten products in sample order.
+__device__ __forceinline__ void score_six(const PairArgs& a, int b, int lane, const float4* s_up, const PairGeo* geo,
+                                          const int* p6, int n, double (*mid6)[10]) {
+    const int cs = lane / 10, i = lane - cs * 10;
+    double mid = 0.0;
+    int k = -1;
+    if (cs < n) k = geo[cs].k;
+    if (k >= 0) {
+        const PairGeo g = geo[cs];
+        mid = pair_sample(a, b, g, i, s_up);
+    }
+    if (cs < 6) mid6[cs][i] = mid;
+    __builtin_amdgcn_wave_barrier();
+    if (k >= 0 && i == 0) {
+        // sequential sum over the ten samples, as builtin sum() does
+        const double* m = mid6[cs];
+        double acc = 0.0 + m[0];
+        int n_above = m[0] > a.thr;
+#pragma unroll
+        for (int s2 = 1; s2 < PD_MID; ++s2) {
+            acc = acc + m[s2];
+            n_above += m[s2] > a.thr;
+        }
+        const double score = acc / 10.0 + geo[cs].prior;
+        a.pair_score[(size_t)b * a.max_pairs + p6[cs]] = (n_above > 8 && score > 0.0) ? score : -1.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Every wavefront works on its own.  The kernel is bound by the latency of the sample
 // gathers (every tap of every sample is a cache line of its own in the (h, w, 38)
 // layout), so a wavefront takes few pairs and many wavefronts are in flight.
+// Images with few candidate pairs (every wavefront gets at most two chunks of six): the
+// chunks are scored directly.  Images with many: most candidates join unrelated peaks
+// and fail at any sample between them, and a pair with two samples at or under the
+// threshold is rejected whatever the others say -- so one lane per pair first takes
+// samples 4 and 5, and only the pairs that pass at least one of them are scored in full.
 // The grid is one-dimensional and swizzled so that the workgroups of one image run on
 // one XCD (workgroup i goes to XCD i % 8) and its PAF map stays in that XCD's L2.
 __global__ void __launch_bounds__(256)
@@ -88,7 +239,8 @@ k_pair_scores(PairArgs a) {
     __shared__ int32_t s_off[PD_N_LIMBS + 1];
     __shared__ int32_t s_cnt[PD_N_PARTS];
     __shared__ float4 s_up[8];
-    __shared__ PairGeo s_geo[4][PAIRS_PER_CHUNK];
+    __shared__ PairGeo s_geo[4][PRE_PAIRS];  // a wavefront's staged pairs: six at a time, or the pre-test's survivors
+    __shared__ int s_p[4][PRE_PAIRS];
     __shared__ double s_mid[4][6][10];
     const int tid = threadIdx.x;
     const int per_xcd = gridDim.x / 8;  // the grid is a multiple of 8 workgroups
@@ -107,121 +259,52 @@ k_pair_scores(PairArgs a) {
         return;
     }
     const int lane = tid & 63, wv = tid >> 6;
-    const int cs = lane / 10, i = lane - cs * 10;  // sample phase: group and sample index
-    const int H = a.src.H, W = a.src.W;
-    const size_t npx = (size_t)H * W;
     const int n_waves = a.per_image * 4;
+    const int wave_id = blk * 4 + wv;
     PairGeo* geo = s_geo[wv];
-    for (int base = (blk * 4 + wv) * PAIRS_PER_CHUNK; base < total; base += n_waves * PAIRS_PER_CHUNK) {
-        // ---- geometry: lane = pair ----
-        if (lane < PAIRS_PER_CHUNK) {
-            const int p = base + lane;
+    int* pq = s_p[wv];
+    if (total <= 2 * n_waves * PAIRS_PER_CHUNK) {
+        for (int base = wave_id * PAIRS_PER_CHUNK; base < total; base += n_waves * PAIRS_PER_CHUNK) {
+            if (lane < PAIRS_PER_CHUNK) {
+                PairGeo g;
+                g.k = -1;
+                const int p = base + lane;
+                if (p < total && !pair_geometry(a, b, p, s_off, s_cnt, g)) a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
+                geo[lane] = g;
+                pq[lane] = p;
+            }
+            __builtin_amdgcn_wave_barrier();  // the staging area is private to this wavefront
+            score_six(a, b, lane, s_up, geo, pq, min(PAIRS_PER_CHUNK, total - base), s_mid[wv]);
+        }
+        return;
+    }
+    for (int base = wave_id * PRE_PAIRS; base < total; base += n_waves * PRE_PAIRS) {
+        int nq = 0;
+        for (int r = 0; r < PRE_PAIRS / 64; ++r) {
+            const int p = base + r * 64 + lane;
+            bool survives = false;
             PairGeo g;
             g.k = -1;
-            g.u0 = g.u1 = g.sy = g.sx = g.prior = 0.0;
-            g.ya = g.xa = g.yb = g.xb = g.pad = 0;
             if (p < total) {
-                int k = 0;
-#pragma unroll
-                for (int d = 16; d >= 1; d >>= 1)
-                    if (k + d <= PD_N_LIMBS - 1 && s_off[k + d] <= p) k += d;
-                const int pa = pd_limb_from(k), pb = pd_limb_to(k);
-                const int nB = s_cnt[pb];
-                const int local = p - s_off[k];
-                const int ia = local / nB, ib = local - ia * nB;
-                const size_t oa = ((size_t)b * PD_N_PARTS + pa) * a.PK + ia;
-                const size_t ob = ((size_t)b * PD_N_PARTS + pb) * a.PK + ib;
-                g.ya = a.pk_y[oa];
-                g.xa = a.pk_x[oa];
-                g.yb = a.pk_y[ob];
-                g.xb = a.pk_x[ob];
-                const long long dy = (long long)g.yb - g.ya, dx = (long long)g.xb - g.xa;
-                const double d2 = (double)(dy * dy + dx * dx);
-                double norm = sqrt(d2);
-                bool skip = false;
-                if (a.mode == PD_MODE_P)
-                    skip = d2 == 0.0;  // coincident peaks, utils/postprocess.py:112
-                else
-                    norm = fmax(norm, 1e-5);  // predict.py:141
-                const double uy = (double)dy / norm, ux = (double)dx / norm;
-                if (a.mode == PD_MODE_P) {  // channel 2k pairs with dy, 2k+1 with dx
-                    g.u0 = uy;
-                    g.u1 = ux;
-                } else {                    // channel 2k pairs with dx, 2k+1 with dy
-                    g.u0 = ux;
-                    g.u1 = uy;
+                if (!pair_geometry(a, b, p, s_off, s_cnt, g)) {
+                    a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
+                } else {
+                    const double m4 = pair_sample(a, b, g, 4, s_up), m5 = pair_sample(a, b, g, 5, s_up);
+                    survives = (m4 > a.thr) || (m5 > a.thr);
+                    if (!survives) a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
                 }
-                g.sy = (double)dy / 9.0;
-                g.sx = (double)dx / 9.0;
-                g.prior = fmin(0.5 * (double)H / norm - 1.0, 0.0);
-                g.k = skip ? -1 : k;
-                if (skip) a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
             }
-            geo[lane] = g;
+            const unsigned long long m = __ballot(survives);
+            if (survives) {
+                const int at = nq + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                geo[at] = g;
+                pq[at] = p;
+            }
+            nq += __builtin_popcountll(m);
         }
-        __builtin_amdgcn_wave_barrier();  // the staging area is private to this wavefront
-        // ---- samples: ten lanes per pair, six pairs per pass ----
-        for (int pass = 0; pass < PAIRS_PER_CHUNK / 6; ++pass) {
-            const int q = pass * 6 + cs;
-            const bool act = cs < 6 && base + q < total;
-            double mid = 0.0;
-            int k = -1;
-            if (act) k = geo[q].k;
-            if (k >= 0) {
-                const PairGeo g = geo[q];
-                double py, px;
-                if (i == PD_MID - 1) {
-                    py = (double)g.yb;
-                    px = (double)g.xb;
-                } else {
-                    py = (double)i * g.sy + (double)g.ya;
-                    px = (double)i * g.sx + (double)g.xa;
-                }
-                int iy, ix;
-                if (a.mode == PD_MODE_P) {
-                    iy = (int)py;
-                    ix = (int)px;
-                } else {
-                    iy = (int)rint(py);
-                    ix = (int)rint(px);
-                }
-                iy = pd_clampi(iy, 0, H - 1);
-                ix = pd_clampi(ix, 0, W - 1);
-                double v0, v1;
-                if (a.src.kind == PD_SRC_LOWRES) {
-                    float f0, f1;
-                    if (a.pairs)
-                        bicubic2_at(a.pairs + ((size_t)b * PD_N_LIMBS + k) * a.src.h * a.src.w * 2, a.src.h, a.src.w, 2,
-                                    0, iy, ix, s_up, &f0, &f1);
-                    else
-                        bicubic2_at(a.src.lo + (size_t)b * a.src.h * a.src.w * a.src.C, a.src.h, a.src.w, a.src.C,
-                                    2 * k, iy, ix, s_up, &f0, &f1);
-                    v0 = (double)f0;
-                    v1 = (double)f1;
-                } else {
-                    const double* pl = a.src.full + ((size_t)b * a.src.Cfull + 2 * k) * npx + (size_t)iy * W + ix;
-                    v0 = pl[0];
-                    v1 = pl[npx];
-                }
-                mid = v0 * g.u0 + v1 * g.u1;
-            }
-            if (cs < 6) s_mid[wv][cs][i] = mid;
-            __builtin_amdgcn_wave_barrier();
-            if (k >= 0 && i == 0) {
-                // sequential sum over the ten samples, as builtin sum() does
-                const double* m = s_mid[wv][cs];
-                double acc = 0.0 + m[0];
-                int n_above = m[0] > a.thr;
-#pragma unroll
-                for (int s2 = 1; s2 < PD_MID; ++s2) {
-                    acc = acc + m[s2];
-                    n_above += m[s2] > a.thr;
-                }
-                const double score = acc / 10.0 + geo[q].prior;
-                a.pair_score[(size_t)b * a.max_pairs + base + q] = (n_above > 8 && score > 0.0) ? score : -1.0;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        __builtin_amdgcn_wave_barrier();
+        for (int q0 = 0; q0 < nq; q0 += PAIRS_PER_CHUNK)
+            score_six(a, b, lane, s_up, geo + q0, pq + q0, min(PAIRS_PER_CHUNK, nq - q0), s_mid[wv]);
     }
 }
 
