@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libposedecode.so')
+LIB_PATH = os.environ.get('PD_LIBRARY') or os.path.join(_HERE, 'libposedecode.so')   # PD_LIBRARY: another build of it
 
 PD_OK, PD_E_INVALID, PD_E_HIP, PD_E_OVERFLOW, PD_E_INDEX, PD_E_STATE = 0, -1, -2, -3, -4, -5
 MODE_P, MODE_D = 0, 1
