@@ -301,7 +301,11 @@ def main():
                          'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': sm_n,
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'measured': 'HIP event pair around the kernel in every step of the timed region, '
-                                     '%d decodes in flight on the chip' % len(engs)},
+                                     '%d decodes in flight on the chip' % len(engs),
+                         'note': 'algorithmic bytes are those of the reference\'s materialising upsample + Gaussian + NMS '
+                                 'pass, which this kernel replaces on the few percent of the map that can hold a peak: '
+                                 'frac > 1 means faster than that pass could run at HBM peak; the kernel itself is '
+                                 'bound by vector-ALU issue (profiles/*sq_counters*), its HBM traffic is `traffic`'},
             'job_hbm_frac_per_gpu': (value / world) * job_bytes / 1e9 / HBM_PEAK_GBS,
             'stage_ms_per_launch_untimed_pass': {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
