@@ -169,54 +169,161 @@ struct ScaleSrc {
 struct AvgArgs {
     ScaleSrc s[PD_MAX_SCALES];
     int n_scales, C, H, W;
-    float n_div;
-    double* dst;       // planar (B, C, H, W)
+    float n_div, n_rcp;   // number of scales; its reciprocal when that is exact (a power of two)
+    double* dst;          // planar (B, C, H, W)
 };
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
-#define AVG_CH 8  // channels per thread: taps and weights of a pixel are set up once per scale for all of them
+#ifndef AVG_TW
+#define AVG_TW 32       // output tile of a workgroup: AVG_TW x AVG_TH = 256 pixels
+#endif
+#define AVG_TH (256 / AVG_TW)
+#ifndef AVG_CH
+#define AVG_CH 4        // channels per workgroup: taps and weights of a pixel are set up once per scale for all of
+#endif                  // them; with 8 the kernel needs 182 registers and two workgroups per CU cannot hide its loads
+#ifndef AVG_SLOTS
+#define AVG_SLOTS 6     // patch elements per thread and channel
+#endif
+#define AVG_PATCH (AVG_SLOTS * 256)
+
+// What a scale contributes to the workgroup's 32 x 8 output tile, fetched ahead of its use.
+// Patch form: the part of the x8 map the tile's taps fall in, rows r_lo .. r_lo+ph-1 and
+// columns c_lo .. c_lo+pw-1, read with coalesced loads (element e = row * pw + col, thread
+// tid takes e = tid + 256 s) and handed to the other threads through LDS.  An identity
+// scale is the thread's own pixel; a patch beyond AVG_PATCH elements (a downscale by more
+// than 2.1) is not staged: its taps are gathered from memory.
+struct AvgFetch {
+    int kind;  // 0 identity, 1 patch, 2 gather
+    int r_lo, c_lo, ph, pw;
+    float v[AVG_SLOTS][AVG_CH];
+};
+
+__device__ __forceinline__ void avg_fetch(const AvgArgs& a, int m, int b, int ch0, int nch, int X0, int Y0, int X, int Y,
+                                          bool inside, int tid, AvgFetch& f) {
+    const ScaleSrc& sc = a.s[m];
+    const size_t plane = (size_t)sc.Hs * sc.Ws;
+    const float* p = sc.up + ((size_t)b * a.C + ch0) * plane;
+    if (sc.identity) {
+        f.kind = 0;
+        const size_t o = (size_t)Y * sc.Ws + X;
+#pragma unroll
+        for (int c = 0; c < AVG_CH; ++c) f.v[0][c] = (inside && c < nch) ? p[c * plane + o] : 0.f;
+        return;
+    }
+    // the offsets grow with the output coordinate: the tile's first and last give the range
+    const int y_first = sc.ty.ofs[Y0], y_last = sc.ty.ofs[min(Y0 + AVG_TH - 1, a.H - 1)];
+    const int x_first = sc.tx.ofs[X0], x_last = sc.tx.ofs[min(X0 + AVG_TW - 1, a.W - 1)];
+    f.r_lo = pd_clampi(y_first, 0, sc.crop_h - 1);
+    f.c_lo = pd_clampi(x_first, 0, sc.crop_w - 1);
+    f.ph = pd_clampi(y_last + 3, 0, sc.crop_h - 1) - f.r_lo + 1;
+    f.pw = pd_clampi(x_last + 3, 0, sc.crop_w - 1) - f.c_lo + 1;
+    if (f.ph * f.pw > AVG_PATCH) {
+        f.kind = 2;
+        return;
+    }
+    f.kind = 1;
+    const int pe = f.ph * f.pw;
+#pragma unroll
+    for (int s = 0; s < AVG_SLOTS; ++s) {
+        const int e = tid + 256 * s;
+        const int row = e / f.pw, col = e - row * f.pw;
+        const float* g = p + (size_t)(f.r_lo + row) * sc.Ws + f.c_lo + col;
+#pragma unroll
+        for (int c = 0; c < AVG_CH; ++c) f.v[s][c] = (e < pe && c < nch) ? g[c * plane] : 0.f;
+    }
+}
+
+// v / n as the reference's float32 division rounds it; for a power of two the product with
+// the reciprocal is the same number.
+template <bool POW2>
+__device__ __forceinline__ float avg_share(float v, const AvgArgs& a) {
+    return POW2 ? v * a.n_rcp : v / a.n_div;
+}
+
+template <bool POW2>
 __global__ void __launch_bounds__(256)
 k_resize_avg(AvgArgs a) {
-    // a workgroup covers a 32 x 8 tile of outputs, so that the rows of the x8 maps it draws
-    // on are re-read from the first-level cache
+    __shared__ __align__(16) float patch[AVG_CH][AVG_PATCH];
     const size_t n = (size_t)a.H * a.W;
     // Workgroup i runs on XCD i % 8, each with an L2 of its own: XCD x takes the x-th eighth
     // of the tiles in row-major order, so that tiles sharing rows and lines share an L2.
-    const int tiles_x = (a.W + 31) / 32, tiles = tiles_x * ((a.H + 7) / 8);
+    const int tiles_x = (a.W + AVG_TW - 1) / AVG_TW, tiles = tiles_x * ((a.H + AVG_TH - 1) / AVG_TH);
     const int per_xcd = (tiles + 7) / 8;
     const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile >= tiles) return;
-    const int X = (tile % tiles_x) * 32 + (threadIdx.x & 31);
-    const int Y = (tile / tiles_x) * 8 + (threadIdx.x >> 5);
-    if (X >= a.W || Y >= a.H) return;
+    const int tid = threadIdx.x;
+    const int X0 = (tile % tiles_x) * AVG_TW, Y0 = (tile / tiles_x) * AVG_TH;
+    const bool inside = X0 + (tid % AVG_TW) < a.W && Y0 + (tid / AVG_TW) < a.H;
+    // threads beyond the map keep step with the others (they load and stage, and store nothing)
+    const int X = min(X0 + (tid % AVG_TW), a.W - 1), Y = min(Y0 + (tid / AVG_TW), a.H - 1);
     const size_t i = (size_t)Y * a.W + X;
     const int ch0 = blockIdx.y * AVG_CH, b = blockIdx.z;
     const int nch = min(AVG_CH, a.C - ch0);
     double acc[AVG_CH];
 #pragma unroll
     for (int c = 0; c < AVG_CH; ++c) acc[c] = 0.0;
+    AvgFetch f;
+    avg_fetch(a, 0, b, ch0, nch, X0, Y0, X, Y, inside, tid, f);
     for (int m = 0; m < a.n_scales; ++m) {
         const ScaleSrc& sc = a.s[m];
-        const size_t plane = (size_t)sc.Hs * sc.Ws;
-        const float* p = sc.up + ((size_t)b * a.C + ch0) * plane;
-        if (sc.identity) {
-            const size_t o = (size_t)Y * sc.Ws + X;
+        const int kind = f.kind, r_lo = f.r_lo, c_lo = f.c_lo, pw = f.pw;
+        if (kind == 0) {
 #pragma unroll
             for (int c = 0; c < AVG_CH; ++c)
-                if (c < nch) acc[c] = acc[c] + (double)(p[c * plane + o] / a.n_div);
+                if (c < nch) acc[c] = acc[c] + (double)avg_share<POW2>(f.v[0][c], a);
+            if (m + 1 < a.n_scales) avg_fetch(a, m + 1, b, ch0, nch, X0, Y0, X, Y, inside, tid, f);
+            continue;
+        }
+        if (kind == 1) {
+            const int pe = f.ph * f.pw;
+#pragma unroll
+            for (int s = 0; s < AVG_SLOTS; ++s) {
+                const int e = tid + 256 * s;
+                if (e < pe) {
+#pragma unroll
+                    for (int c = 0; c < AVG_CH; ++c) patch[c][e] = f.v[s][c];
+                }
+            }
+        }
+        __syncthreads();
+        // the next scale's loads are in flight while this one is evaluated
+        if (m + 1 < a.n_scales) avg_fetch(a, m + 1, b, ch0, nch, X0, Y0, X, Y, inside, tid, f);
+        const int x0 = sc.tx.ofs[X], y0 = sc.ty.ofs[Y];
+        const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)X);
+        const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Y);
+        const int xi0 = pd_clampi(x0, 0, sc.crop_w - 1), xi1 = pd_clampi(x0 + 1, 0, sc.crop_w - 1),
+                  xi2 = pd_clampi(x0 + 2, 0, sc.crop_w - 1), xi3 = pd_clampi(x0 + 3, 0, sc.crop_w - 1);
+        // away from the left and right border the four taps are adjacent
+        const bool adjacent = x0 >= 0 && x0 + 3 <= sc.crop_w - 1;
+        if (kind == 1) {
+            int ro[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ro[k] = (pd_clampi(y0 + k, 0, sc.crop_h - 1) - r_lo) * pw - c_lo;
+#pragma unroll
+            for (int c = 0; c < AVG_CH; ++c) {
+                if (c < nch) {
+                    const float* q = patch[c];
+                    float hv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float* row = q + ro[k];
+                        if (adjacent) {
+                            const float4u t = *(const float4u*)(row + x0);
+                            hv[k] = ((t.x * ac.x + t.y * ac.y) + t.z * ac.z) + t.w * ac.w;
+                        } else {
+                            hv[k] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
+                        }
+                    }
+                    const float v = ((hv[0] * bc.x + hv[1] * bc.y) + hv[2] * bc.z) + hv[3] * bc.w;
+                    acc[c] = acc[c] + (double)avg_share<POW2>(v, a);
+                }
+            }
         } else {
-            const int x0 = sc.tx.ofs[X], y0 = sc.ty.ofs[Y];
-            const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)X);
-            const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Y);
-            const int xi0 = pd_clampi(x0, 0, sc.crop_w - 1), xi1 = pd_clampi(x0 + 1, 0, sc.crop_w - 1),
-                      xi2 = pd_clampi(x0 + 2, 0, sc.crop_w - 1), xi3 = pd_clampi(x0 + 3, 0, sc.crop_w - 1);
+            const size_t plane = (size_t)sc.Hs * sc.Ws;
+            const float* p = sc.up + ((size_t)b * a.C + ch0) * plane;
             int ro[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) ro[k] = pd_clampi(y0 + k, 0, sc.crop_h - 1) * sc.Ws;
-            // away from the left and right border the four taps are adjacent: one 16-byte load
-            // (4-byte aligned) instead of four loads -- the kernel is bound by the number of
-            // load instructions, not by their bytes
-            const bool adjacent = x0 >= 0 && x0 + 3 <= sc.crop_w - 1;
 #pragma unroll
             for (int c = 0; c < AVG_CH; ++c) {
                 if (c < nch) {
@@ -233,11 +340,13 @@ k_resize_avg(AvgArgs a) {
                         }
                     }
                     const float v = ((hv[0] * bc.x + hv[1] * bc.y) + hv[2] * bc.z) + hv[3] * bc.w;
-                    acc[c] = acc[c] + (double)(v / a.n_div);
+                    acc[c] = acc[c] + (double)avg_share<POW2>(v, a);
                 }
             }
         }
+        __syncthreads();  // the patch is free for the next scale
     }
+    if (!inside) return;
     double* out = a.dst + ((size_t)b * a.C + ch0) * n + i;
 #pragma unroll
     for (int c = 0; c < AVG_CH; ++c)
@@ -281,9 +390,15 @@ int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, 
     a.W = W;
     a.n_div = (float)n_scales;
     a.dst = dst;
-    const unsigned tiles = (unsigned)(((W + 31) / 32) * ((H + 7) / 8));
+    const unsigned tiles = (unsigned)(((W + AVG_TW - 1) / AVG_TW) * ((H + AVG_TH - 1) / AVG_TH));
     pd_prof_begin(ctx, PD_STAGE_RESIZE);
-    hipLaunchKernelGGL(k_resize_avg, dim3((tiles + 7) / 8 * 8, (C + AVG_CH - 1) / AVG_CH, B), dim3(256), 0, ctx->stream, a);
+    const dim3 grid((tiles + 7) / 8 * 8, (C + AVG_CH - 1) / AVG_CH, B);
+    if ((n_scales & (n_scales - 1)) == 0) {
+        a.n_rcp = 1.0f / (float)n_scales;
+        hipLaunchKernelGGL(k_resize_avg<true>, grid, dim3(256), 0, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_resize_avg<false>, grid, dim3(256), 0, ctx->stream, a);
+    }
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;

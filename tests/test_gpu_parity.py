@@ -313,11 +313,13 @@ def test_resize_matches_oracle_bitwise(pdec, hs, ws, crop, out):
     eng.close()
 
 
-def test_multiscale_average_and_decode(pdec):
-    """predict.py:49-72 with the four test scales, then the mode-D decode."""
+@pytest.mark.parametrize('scales', [[0.5, 1.0, 1.5, 2.0],      # the reference's test scales; 1/4 is exact
+                                    [0.7, 1.0, 1.3],           # three scales: a true float32 division by 3
+                                    [1.0, 2.6]])               # a downscale by 2.6: patches too large to stage
+def test_multiscale_average_and_decode(pdec, scales):
+    """predict.py:49-72, then the mode-D decode."""
     from poseestimation_amd import synth
     H = W = 184
-    scales = [0.5, 1.0, 1.5, 2.0]
     outs = [synth.scene(H, W, 2, 31, paf_order='xy', scale=s) for s in scales]
     heats = [o[0] for o in outs]
     pafs = [o[1] for o in outs]
