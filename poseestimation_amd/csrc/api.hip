@@ -473,6 +473,7 @@ extern "C" int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t ca
         // Such a context therefore launches eagerly from now on.
         ctx->use_graph = 0;
         if (ctx->graph_exec) {
+            PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
             PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
             PD_HIP(ctx, hipGraphExecDestroy(ctx->graph_exec));
             ctx->graph_exec = nullptr;
@@ -767,6 +768,7 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
 
 // ---- pd_submit: the same decode, launched by a thread of the context's own -----------
 static void worker_main(pd_ctx* ctx) {
+    (void)hipSetDevice(ctx->cfg.device_id);  // a new thread starts on device 0
     for (;;) {
         SubmitJob job;
         {
