@@ -20,11 +20,19 @@ if os.environ.get('PD_GC') == 'off':
     import gc
     gc.collect(); gc.freeze()
 pend = []
+THREADS = os.environ.get('PD_SUBMIT') == '1'   # launches issued by the contexts' launcher threads
+def fetch(e):
+    if THREADS:
+        e.ctx.flush()
+    return e.ctx.fetch()
 def step(i):
     e = engs[i % NC]
     if len(pend) == NC:
-        pend.pop(0).ctx.fetch()
-    e.enqueue_device(dh.data_ptr(), dp.data_ptr(), B, H // 8, W // 8, (H, W))
+        fetch(pend.pop(0))
+    if THREADS:
+        e.ctx.submit(dh.data_ptr(), dp.data_ptr(), B, H // 8, W // 8, H, W, 0.1, 0.05)
+    else:
+        e.enqueue_device(dh.data_ptr(), dp.data_ptr(), B, H // 8, W // 8, (H, W))
     pend.append(e)
 for i in range(5 * NC):
     step(i)
@@ -35,7 +43,7 @@ for i in range(N):
     if (i + 1) % 100 == 0:
         marks.append(time.perf_counter())
 while pend:
-    pend.pop(0).ctx.fetch()
+    fetch(pend.pop(0))
 us = [(b - a) / 100 * 1e6 for a, b in zip(marks, marks[1:])]
 print('us per step by window of 100:', ' '.join('%.0f' % u for u in us))
 print('mean', sum(us) / len(us), 'min', min(us), 'max', max(us))
