@@ -248,6 +248,16 @@ void pd_prof_end(pd_ctx* ctx);
 
 __device__ __forceinline__ int pd_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Orders the LDS (and memory) accesses of one wavefront's lanes among themselves: the
+// hardware executes a wavefront's LDS instructions in order, so all that is needed is that
+// the compiler keeps them in program order across this point.  For code whose LDS area
+// belongs to a single wavefront, in place of a workgroup barrier.
+__device__ __forceinline__ void pd_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
 // scipy mode='reflect' index (d c b a | a b c d | d c b a) for any offset.
 __device__ __forceinline__ int pd_reflect(int i, int n) {
     if (i >= 0 && i < n) return i;

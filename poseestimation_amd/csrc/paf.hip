@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "match.h"
 
 #pragma clang fp contract(off)
 
@@ -311,180 +312,10 @@ k_pair_scores(PairArgs a) {
 // ---------------------------------------------------------------------------------
 // Matching: one wavefront per (image, limb).
 // ---------------------------------------------------------------------------------
-struct MatchArgs {
-    int PK, max_pairs, cap;  // cap: candidates sorted in LDS (power of two)
-    const double* pair_score;
-    const int32_t* pair_off;
-    const int32_t* part_count;
-    const int32_t* pk_id;
-    const double* pk_score;
-    pd_conn* conn;
-    double* conn_conf;
-    int32_t* limb_count;
-};
-
-__device__ __forceinline__ bool cand_before(double sa, int ia, double sb, int ib) {
-    return sa > sb || (sa == sb && ia < ib);
-}
-
 __global__ void __launch_bounds__(64)
 k_match(MatchArgs a) {
     extern __shared__ __align__(16) unsigned char dyn[];
-    double* s_score = (double*)dyn;
-    int32_t* s_idx = (int32_t*)(dyn + (size_t)a.cap * 8);
-    unsigned char* usedA = dyn + (size_t)a.cap * 12;
-    unsigned char* usedB = usedA + a.PK;
-    const int k = blockIdx.x, b = blockIdx.y;
-    const int lane = threadIdx.x;
-    const int pa = pd_limb_from(k), pb = pd_limb_to(k);
-    const int nA = a.part_count[b * PD_N_PARTS + pa], nB = a.part_count[b * PD_N_PARTS + pb];
-    int32_t* out_count = a.limb_count + b * PD_N_LIMBS + k;
-    if (nA == 0 || nB == 0) {  // utils/postprocess.py:92-95
-        if (lane == 0) *out_count = -1;
-        return;
-    }
-    if (a.pair_off[b * (PD_N_LIMBS + 1) + PD_N_LIMBS] < 0) {  // pair capacity exceeded, image flagged
-        if (lane == 0) *out_count = 0;
-        return;
-    }
-    const int off = a.pair_off[b * (PD_N_LIMBS + 1) + k];
-    const int npairs = a.pair_off[b * (PD_N_LIMBS + 1) + k + 1] - off;
-    const double* ps = a.pair_score + (size_t)b * a.max_pairs + off;
-    for (int i = lane; i < a.PK; i += 64) {
-        usedA[i] = 0;
-        usedB[i] = 0;
-    }
-    // compact the surviving candidates, keeping a-major / b-minor order
-    int total = 0;
-    for (int base = 0; base < npairs; base += 64) {
-        const int i = base + lane;
-        const double s = i < npairs ? ps[i] : -1.0;
-        const bool ok = s > 0.0;
-        const unsigned long long m = __ballot(ok);
-        const int pos = total + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (ok && pos < a.cap) {
-            s_score[pos] = s;
-            s_idx[pos] = i;
-        }
-        total += __builtin_popcountll(m);
-    }
-    const int limit = nA < nB ? nA : nB;
-    pd_conn* rows = a.conn + ((size_t)b * PD_N_LIMBS + k) * a.PK;
-    double* conf = a.conn_conf + ((size_t)b * PD_N_LIMBS + k) * a.PK * 2;
-    const int32_t* idA = a.pk_id + ((size_t)b * PD_N_PARTS + pa) * a.PK;
-    const int32_t* idB = a.pk_id + ((size_t)b * PD_N_PARTS + pb) * a.PK;
-    const double* scA = a.pk_score + ((size_t)b * PD_N_PARTS + pa) * a.PK;
-    const double* scB = a.pk_score + ((size_t)b * PD_N_PARTS + pb) * a.PK;
-    int count = 0;
-    __syncthreads();
-    if (total <= a.cap) {
-        // wave-level bitonic sort on (score descending, pair index ascending)
-        int n2 = 64;
-        while (n2 < total) n2 <<= 1;
-        for (int i = total + lane; i < n2; i += 64) {
-            s_score[i] = -INFINITY;
-            s_idx[i] = 0x7fffffff;
-        }
-        __syncthreads();
-        for (int kk = 2; kk <= n2; kk <<= 1) {
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int t = lane; t < n2; t += 64) {
-                    const int q = t ^ j;
-                    if (q > t) {
-                        const double st = s_score[t], sq = s_score[q];
-                        const int it = s_idx[t], iq = s_idx[q];
-                        const bool fwd = (t & kk) == 0;
-                        const bool t_first = cand_before(st, it, sq, iq);
-                        if (fwd ? !t_first : t_first) {
-                            s_score[t] = sq;
-                            s_idx[t] = iq;
-                            s_score[q] = st;
-                            s_idx[q] = it;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        // greedy pick, 64 sorted candidates at a time: the first lane whose two
-        // peaks are still free wins, then the others re-check
-        for (int base = 0; base < total && count < limit; base += 64) {
-            const int i = base + lane;
-            bool have = i < total;
-            const int idx = have ? s_idx[i] : 0;
-            const double sc = have ? s_score[i] : 0.0;
-            const int ia = idx / nB, ib = idx - ia * nB;
-            // every lane fetches what a pick of its candidate would store, so that the
-            // pick loop itself waits for no memory
-            pd_conn r;
-            r.id_a = have ? idA[ia] : 0;
-            r.id_b = have ? idB[ib] : 0;
-            r.ia = ia;
-            r.ib = ib;
-            r.score = sc;
-            const double conf_a = have ? scA[ia] : 0.0, conf_b = have ? scB[ib] : 0.0;
-            while (count < limit) {
-                const bool ok = have && !usedA[ia] && !usedB[ib];
-                const unsigned long long m = __ballot(ok);
-                if (m == 0ull) break;
-                const int first = __builtin_ctzll(m);
-                if (lane == first) {
-                    rows[count] = r;
-                    conf[2 * count] = conf_a;
-                    conf[2 * count + 1] = conf_b;
-                    usedA[ia] = 1;
-                    usedB[ib] = 1;
-                    have = false;
-                }
-                ++count;
-                __syncthreads();
-            }
-        }
-    } else {
-        // more survivors than the LDS list holds: repeated arg-max over the pair
-        // scores in memory (the same picks as sort + greedy, in the same order)
-        while (count < limit) {
-            double best = -1.0;
-            int best_i = 0x7fffffff;
-            for (int i = lane; i < npairs; i += 64) {
-                const double s = ps[i];
-                if (s > 0.0) {
-                    const int ia = i / nB, ib = i - ia * nB;
-                    if (!usedA[ia] && !usedB[ib] && cand_before(s, i, best, best_i)) {
-                        best = s;
-                        best_i = i;
-                    }
-                }
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const double os = __shfl_xor(best, d);
-                const int oi = __shfl_xor(best_i, d);
-                if (cand_before(os, oi, best, best_i)) {
-                    best = os;
-                    best_i = oi;
-                }
-            }
-            if (!(best > 0.0)) break;
-            const int ia = best_i / nB, ib = best_i - ia * nB;
-            if (lane == 0) {
-                pd_conn r;
-                r.id_a = idA[ia];
-                r.id_b = idB[ib];
-                r.ia = ia;
-                r.ib = ib;
-                r.score = best;
-                rows[count] = r;
-                conf[2 * count] = scA[ia];
-                conf[2 * count + 1] = scB[ib];
-                usedA[ia] = 1;
-                usedB[ib] = 1;
-            }
-            ++count;
-            __syncthreads();
-        }
-    }
-    if (lane == 0) *out_count = count;
+    match_limb(a, blockIdx.x, blockIdx.y, threadIdx.x, dyn);
 }
 
 // (B, h, w, 38) -> (B, 19, h, w, 2): the two channels of a limb side by side, pixels of a
@@ -565,7 +396,7 @@ int pd_launch_match(pd_ctx* ctx) {
     a.conn = ctx->conn;
     a.conn_conf = ctx->conn_conf;
     a.limb_count = ctx->limb_count;
-    const size_t lds = (size_t)a.cap * 12 + 2 * (size_t)a.PK;
+    const size_t lds = pd_match_lds(a.cap, a.PK);
     pd_prof_begin(ctx, PD_STAGE_MATCH);
     hipLaunchKernelGGL(k_match, dim3(PD_N_LIMBS, ctx->B), dim3(64), lds, ctx->stream, a);
     pd_prof_end(ctx);

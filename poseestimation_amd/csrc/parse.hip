@@ -145,27 +145,53 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(64)
-k_parse_wave(ParseArgs a) {
-    __shared__ int ids[PD_N_PARTS][64];
-    __shared__ __align__(16) double c_all[WAVE_CONNS * 4];  // staged connections; the table form's rows on hand-over
-    double* c_score = c_all;
-    double* c_ca = c_all + WAVE_CONNS;
-    double* c_cb = c_all + 2 * WAVE_CONNS;
-    int* c_ida = (int*)(c_all + 3 * WAVE_CONNS);
-    int* c_idb = c_ida + WAVE_CONNS;
-    __shared__ short tab_a[WAVE_IDS], tab_b[WAVE_IDS];  // peak id -> connection of the current limb
-    __shared__ short own[64];                            // connection -> the person that matches it
-    __shared__ short newc[64];                           // new person slot -> its connection
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
+// The wavefront's LDS.
+struct WaveShared {
+    int ids[PD_N_PARTS][64];
+    __attribute__((aligned(16))) double c_all[WAVE_CONNS * 4];  // staged connections; the table form's rows on hand-over
+    short tab_a[WAVE_IDS], tab_b[WAVE_IDS];  // peak id -> connection of the current limb
+    short own[64];                           // connection -> the person that matches it
+    short newc[64];                          // new person slot -> its connection
+};
+
+// What the wavefront carries from limb to limb.
+struct WaveState {
+    double my_score;
+    int my_cnt;
+    int n;       // open persons
+    int rc;      // 0 go on, 1 hand the image to the table form, 2 mode-D index error
+    int staged;  // connections staged so far
+};
+
+__device__ __forceinline__ void wave_parse_begin(WaveShared& sh, WaveState& st, int lane) {
     for (int i = lane; i < WAVE_IDS; i += 64) {
-        tab_a[i] = -1;
-        tab_b[i] = -1;
+        sh.tab_a[i] = -1;
+        sh.tab_b[i] = -1;
     }
-    own[lane] = -1;
-    const int my_nc = lane < PD_N_LIMBS ? max(0, a.limb_count[b * PD_N_LIMBS + lane]) : 0;
-    // exclusive prefix of the connection counts over the limbs
+    sh.own[lane] = -1;
+#pragma unroll
+    for (int p = 0; p < PD_N_PARTS; ++p) sh.ids[p][lane] = -1;
+    st.my_score = 0.0;
+    st.my_cnt = 0;
+    st.n = 0;
+    st.rc = 0;
+    st.staged = 0;
+    pd_wave_sync();
+}
+
+// Limbs k0 .. k1-1 of image b: their connections are staged into LDS behind the ones staged
+// before (one round trip to memory), then applied in limb order.
+__device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int lane, int k0, int k1, WaveShared& sh,
+                                                 WaveState& st) {
+    if (st.rc != 0) return;
+    double* c_score = sh.c_all;
+    double* c_ca = sh.c_all + WAVE_CONNS;
+    double* c_cb = sh.c_all + 2 * WAVE_CONNS;
+    int* c_ida = (int*)(sh.c_all + 3 * WAVE_CONNS);
+    int* c_idb = c_ida + WAVE_CONNS;
+    const bool mine = lane >= k0 && lane < k1;
+    const int my_nc = mine ? max(0, a.limb_count[b * PD_N_LIMBS + lane]) : 0;
+    // exclusive prefix of the connection counts over the limbs of this call
     int off = my_nc;
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1) {
@@ -174,16 +200,13 @@ k_parse_wave(ParseArgs a) {
     }
     const int total = __builtin_amdgcn_readlane(off, PD_N_LIMBS - 1);
     off -= my_nc;
-    if (total > WAVE_CONNS) {
-        if (a.only_flagged) {  // the table kernel follows
-            if (lane == 0) a.person_count[b] = -1;
-        } else {
-            parse_table(a, b, lane, c_all);
-        }
+    if (st.staged + total > WAVE_CONNS) {
+        st.rc = 1;
         return;
     }
-    // stage all connections: four per lane in flight, the limb of a flat index found
-    // from the prefix sums held across the lanes
+    const int at0 = st.staged;  // where this call's connections start in the staging area
+    // four connections per lane in flight, the limb of a flat index found from the prefix
+    // sums held across the lanes
     for (int i0 = 0; i0 < total; i0 += 256) {
         pd_conn r[4];
         double cf0[4], cf1[4];
@@ -195,11 +218,11 @@ k_parse_wave(ParseArgs a) {
             if (i < total) {
                 // limbs without connections share their offset with the next one: the scan
                 // lands on the last limb whose offset is <= i, which is the one that holds i
-                int k = 0, off_k = 0;
+                int k = k0, off_k = 0;
 #pragma unroll
                 for (int q = 1; q < PD_N_LIMBS; ++q) {
                     const int oq = __builtin_amdgcn_readlane(off, q);
-                    if (oq <= i) {
+                    if (q > k0 && q < k1 && oq <= i) {
                         k = q;
                         off_k = oq;
                     }
@@ -215,28 +238,27 @@ k_parse_wave(ParseArgs a) {
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * 64 + lane;
             if (i < total) {
-                c_ida[i] = r[u].id_a;
-                c_idb[i] = r[u].id_b;
-                c_score[i] = r[u].score;
-                c_ca[i] = cf0[u];
-                c_cb[i] = cf1[u];
+                c_ida[at0 + i] = r[u].id_a;
+                c_idb[at0 + i] = r[u].id_b;
+                c_score[at0 + i] = r[u].score;
+                c_ca[at0 + i] = cf0[u];
+                c_cb[at0 + i] = cf1[u];
             }
         }
     }
-#pragma unroll
-    for (int p = 0; p < PD_N_PARTS; ++p) ids[p][lane] = -1;
-    __syncthreads();
-    double my_score = 0.0;
-    int my_cnt = 0;
-    int n = 0;
-    int rc = 0;  // 1 = hand over, 2 = mode-D index error
-    for (int k = 0; k < PD_N_LIMBS && rc == 0; ++k) {
-        const int nc = __builtin_amdgcn_readlane(my_nc, k), o = __builtin_amdgcn_readlane(off, k);
+    st.staged += total;
+    pd_wave_sync();
+    double my_score = st.my_score;
+    int my_cnt = st.my_cnt;
+    int n = st.n;
+    int rc = 0;
+    for (int k = k0; k < k1 && rc == 0; ++k) {
+        const int nc = __builtin_amdgcn_readlane(my_nc, k), o = at0 + __builtin_amdgcn_readlane(off, k);
         if (nc == 0) continue;
         const int pa = pd_limb_from(k), pb = pd_limb_to(k);
         // the two id columns this limb tests stay in registers for the whole limb; LDS
         // is written through and only re-read around the (rare) merges
-        int col_a = ids[pa][lane], col_b = ids[pb][lane];
+        int col_a = sh.ids[pa][lane], col_b = sh.ids[pb][lane];
         // Whole limb at once.  When every connection of the limb has its own two peaks
         // (always so for connections that come from the matching stage), every person
         // matches at most one connection and every connection at most one person, the
@@ -250,21 +272,21 @@ k_parse_wave(ParseArgs a) {
             bool fast = __ballot(!in_range) == 0ull;
             if (fast) {
                 if (is_c) {
-                    tab_a[ida] = (short)lane;
-                    tab_b[idb] = (short)lane;
+                    sh.tab_a[ida] = (short)lane;
+                    sh.tab_b[idb] = (short)lane;
                 }
-                __syncthreads();
-                const bool dup = is_c && (tab_a[ida] != lane || tab_b[idb] != lane);
+                pd_wave_sync();
+                const bool dup = is_c && (sh.tab_a[ida] != lane || sh.tab_b[idb] != lane);
                 const bool is_p = lane < n;
-                const int ca = (is_p && col_a >= 0 && col_a < WAVE_IDS) ? tab_a[col_a] : -1;
-                const int cb = (is_p && col_b >= 0 && col_b < WAVE_IDS) ? tab_b[col_b] : -1;
+                const int ca = (is_p && col_a >= 0 && col_a < WAVE_IDS) ? sh.tab_a[col_a] : -1;
+                const int cb = (is_p && col_b >= 0 && col_b < WAVE_IDS) ? sh.tab_b[col_b] : -1;
                 const bool two = ca >= 0 && cb >= 0 && ca != cb;
                 const int mc = ca >= 0 ? ca : cb;
-                if (mc >= 0) own[mc] = (short)lane;
-                __syncthreads();
-                const bool shared_conn = mc >= 0 && own[mc] != lane;
+                if (mc >= 0) sh.own[mc] = (short)lane;
+                pd_wave_sync();
+                const bool shared_conn = mc >= 0 && sh.own[mc] != lane;
                 fast = __ballot(dup || two || shared_conn) == 0ull;
-                const bool unmatched = is_c && own[lane] < 0;
+                const bool unmatched = is_c && sh.own[lane] < 0;
                 const unsigned long long um = __ballot(unmatched);
                 const int n_new = (a.mode == PD_MODE_D || k < 17) ? __builtin_popcountll(um) : 0;
                 const bool room = n + n_new <= 64 && n + n_new <= a.max_persons;
@@ -273,20 +295,20 @@ k_parse_wave(ParseArgs a) {
                         const int tb = c_idb[o + mc];
                         if (col_b != tb) {  // :210 / predict.py:205
                             col_b = tb;
-                            ids[pb][lane] = tb;
+                            sh.ids[pb][lane] = tb;
                             my_cnt += 1;
                             my_score += c_cb[o + mc] + c_score[o + mc];
                         }
                     }
                     if (n_new > 0) {
-                        if (unmatched) newc[__builtin_popcountll(um & ((1ull << lane) - 1ull))] = (short)lane;
-                        __syncthreads();
+                        if (unmatched) sh.newc[__builtin_popcountll(um & ((1ull << lane) - 1ull))] = (short)lane;
+                        pd_wave_sync();
                         if (lane >= n && lane < n + n_new) {  // utils/postprocess.py:196-205 / predict.py:228-244
-                            const int c = newc[lane - n];
+                            const int c = sh.newc[lane - n];
                             col_a = c_ida[o + c];
                             col_b = c_idb[o + c];
-                            ids[pa][lane] = col_a;
-                            ids[pb][lane] = col_b;
+                            sh.ids[pa][lane] = col_a;
+                            sh.ids[pb][lane] = col_b;
                             my_score = (c_ca[o + c] + c_cb[o + c]) + c_score[o + c];
                             my_cnt = 2;
                         }
@@ -295,13 +317,13 @@ k_parse_wave(ParseArgs a) {
                 }
                 // leave the tables clean for the next limb
                 if (is_c) {
-                    tab_a[ida] = -1;
-                    tab_b[idb] = -1;
+                    sh.tab_a[ida] = -1;
+                    sh.tab_b[idb] = -1;
                 }
-                own[lane] = -1;
-                __syncthreads();
+                sh.own[lane] = -1;
+                pd_wave_sync();
                 if (fast && room) continue;
-                if (fast && !room) {  // more than 64 open persons: the table kernel takes the image
+                if (fast && !room) {  // more than 64 open persons: the table form takes the image
                     rc = 1;
                     break;
                 }
@@ -309,9 +331,9 @@ k_parse_wave(ParseArgs a) {
         }
         for (int c0 = 0; c0 < nc && rc == 0; c0 += 64) {
             // this chunk's connections, one per lane, broadcast below with readlane
-            const int mine = min(o + c0 + lane, WAVE_CONNS - 1);
-            const int l_ida = c_ida[mine], l_idb = c_idb[mine];
-            const double l_score = c_score[mine], l_ca = c_ca[mine], l_cb = c_cb[mine];
+            const int mine_at = min(o + c0 + lane, WAVE_CONNS - 1);
+            const int l_ida = c_ida[mine_at], l_idb = c_idb[mine_at];
+            const double l_score = c_score[mine_at], l_ca = c_ca[mine_at], l_cb = c_cb[mine_at];
             const int m_end = min(64, nc - c0);
             for (int s = 0; s < m_end; ++s) {
                 const int ida = __builtin_amdgcn_readlane(l_ida, s), idb = __builtin_amdgcn_readlane(l_idb, s);
@@ -328,8 +350,8 @@ k_parse_wave(ParseArgs a) {
                         if (lane == n) {
                             col_a = ida;
                             col_b = idb;
-                            ids[pa][lane] = ida;
-                            ids[pb][lane] = idb;
+                            sh.ids[pa][lane] = ida;
+                            sh.ids[pb][lane] = idb;
                             my_score = (conf_a + conf_b) + score;
                             my_cnt = 2;
                         }
@@ -339,45 +361,45 @@ k_parse_wave(ParseArgs a) {
                     const int j0 = __builtin_ctzll(m);
                     if (lane == j0 && col_b != idb) {  // :210 / predict.py:205
                         col_b = idb;
-                        ids[pb][lane] = idb;
+                        sh.ids[pb][lane] = idb;
                         my_cnt += 1;
                         my_score += conf_b + score;
                     }
                 } else if (found == 2) {
                     const int j0 = __builtin_ctzll(m), j1 = __builtin_ctzll(m & (m - 1ull));
-                    __syncthreads();  // the table in LDS is complete up to here
-                    const bool both = lane < PD_N_PARTS && ids[lane][j0] >= 0 && ids[lane][j1] >= 0;
+                    pd_wave_sync();  // the table in LDS is complete up to here
+                    const bool both = lane < PD_N_PARTS && sh.ids[lane][j0] >= 0 && sh.ids[lane][j1] >= 0;
                     const bool overlap = __ballot(both) != 0ull;  // is_isolated, :14-16
                     if (!overlap) {
                         // merge person j1 into j0 (:218-222 / predict.py:216-219), delete j1
-                        if (lane < PD_N_PARTS) ids[lane][j0] = (ids[lane][j0] + 1) + ids[lane][j1];
+                        if (lane < PD_N_PARTS) sh.ids[lane][j0] = (sh.ids[lane][j0] + 1) + sh.ids[lane][j1];
                         const double s1 = __shfl(my_score, j1);
                         const int c1 = __shfl(my_cnt, j1);
                         if (lane == j0) {
                             my_score = (my_score + s1) + score;
                             my_cnt += c1;
                         }
-                        __syncthreads();
+                        pd_wave_sync();
                         // close the gap: persons above j1 move down one lane
                         int nxt[PD_N_PARTS];
 #pragma unroll
-                        for (int p = 0; p < PD_N_PARTS; ++p) nxt[p] = ids[p][lane < 63 ? lane + 1 : lane];
+                        for (int p = 0; p < PD_N_PARTS; ++p) nxt[p] = sh.ids[p][lane < 63 ? lane + 1 : lane];
                         const double nxs = __shfl_down(my_score, 1);
                         const int nxc = __shfl_down(my_cnt, 1);
-                        __syncthreads();
+                        pd_wave_sync();
                         if (lane >= j1) {
 #pragma unroll
-                            for (int p = 0; p < PD_N_PARTS; ++p) ids[p][lane] = lane == 63 ? -1 : nxt[p];
+                            for (int p = 0; p < PD_N_PARTS; ++p) sh.ids[p][lane] = lane == 63 ? -1 : nxt[p];
                             my_score = nxs;
                             my_cnt = nxc;
                         }
                         --n;
-                        __syncthreads();
-                        col_a = ids[pa][lane];
-                        col_b = ids[pb][lane];
+                        pd_wave_sync();
+                        col_a = sh.ids[pa][lane];
+                        col_b = sh.ids[pb][lane];
                     } else if (lane == j0 && (a.mode == PD_MODE_P || col_b != idb)) {
                         col_b = idb;  // :210-214 (always) / predict.py:222-225 (if different)
-                        ids[pb][lane] = idb;
+                        sh.ids[pb][lane] = idb;
                         my_cnt += 1;
                         my_score += conf_b + score;
                     }
@@ -387,18 +409,27 @@ k_parse_wave(ParseArgs a) {
                 }
             }
         }
-        __syncthreads();  // this limb's writes are visible before the next limb loads its columns
+        pd_wave_sync();  // this limb's writes are visible before the next limb loads its columns
     }
-    if (rc == 1) {  // more than 64 open persons: the table form redoes this image
+    st.my_score = my_score;
+    st.my_cnt = my_cnt;
+    st.n = n;
+    st.rc = rc;
+}
+
+// Prune and write out, or hand the image over.  No other wavefront of the workgroup may
+// still be running when this is called (the table form uses workgroup barriers).
+__device__ __forceinline__ void wave_parse_end(const ParseArgs& a, int b, int lane, WaveShared& sh, WaveState& st) {
+    if (st.rc == 1) {  // more connections or open persons than the wavefront form holds: the table form redoes this image
         if (a.only_flagged) {
             if (lane == 0) a.person_count[b] = -1;
         } else {
-            __syncthreads();
-            parse_table(a, b, lane, c_all);
+            pd_wave_sync();
+            parse_table(a, b, lane, sh.c_all);
         }
         return;
     }
-    if (rc == 2) {
+    if (st.rc == 2) {
         if (lane == 0) {
             a.person_count[b] = 0;
             if (a.status[b] == PD_OK) a.status[b] = PD_E_INDEX;
@@ -407,16 +438,26 @@ k_parse_wave(ParseArgs a) {
     }
     // prune (:228-232 / predict.py:248-252) and write out in row order
     bool keep = false;
-    if (lane < n) keep = !((double)my_cnt < 4.0 || my_score / (double)my_cnt < 0.4);
+    if (lane < st.n) keep = !((double)st.my_cnt < 4.0 || st.my_score / (double)st.my_cnt < 0.4);
     const unsigned long long m = __ballot(keep);
     if (keep) {
         double* out = a.persons + ((size_t)b * a.max_persons + __builtin_popcountll(m & ((1ull << lane) - 1ull))) * 20;
 #pragma unroll
-        for (int p = 0; p < PD_N_PARTS; ++p) out[p] = (double)ids[p][lane];
-        out[18] = my_score;
-        out[19] = (double)my_cnt;
+        for (int p = 0; p < PD_N_PARTS; ++p) out[p] = (double)sh.ids[p][lane];
+        out[18] = st.my_score;
+        out[19] = (double)st.my_cnt;
     }
     if (lane == 0) a.person_count[b] = __builtin_popcountll(m);
+}
+
+__global__ void __launch_bounds__(64)
+k_parse_wave(ParseArgs a) {
+    __shared__ WaveShared sh;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    WaveState st;
+    wave_parse_begin(sh, st, lane);
+    wave_parse_limbs(a, b, lane, 0, PD_N_LIMBS, sh, st);
+    wave_parse_end(a, b, lane, sh, st);
 }
 
 // ---- packing --------------------------------------------------------------------
