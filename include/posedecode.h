@@ -248,6 +248,38 @@ int pd_set_host_results(pd_ctx* ctx, int enable);
  * overflowed.  Waits for the stream.  No counterpart in the reference; diagnostics. */
 int pd_filter_stats(pd_ctx* ctx, int64_t* out);
 
+/* pd_decode_batch for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * reference (Python, garbage-collected).  The call takes no context, allocates nothing
+ * and frees nothing: all intermediate state (peak lists, counters, candidate-pair scores,
+ * connections, person rows, tap tables) lives in one device array of
+ * PD_STATIC_SCRATCH_BYTES that is part of the library's code object and stays resident on
+ * every GPU the library runs on until the process ends.
+ *
+ * heat (B, h, w, 19) and paf (B, h, w, 38): float32 device arrays, 16-byte aligned.
+ * out: device buffer of out_capacity bytes that receives the packed results in the
+ * layout of pd_results_host (header, count tables, peaks, connections, person rows);
+ * header[4] is the first image whose status is not PD_OK (or -1), header[5] != 0 means
+ * the payload did not fit (header[5] = bytes needed; header and count tables are always
+ * written).  stream: the hipStream_t to launch on (NULL = the default stream); the call
+ * only enqueues, the caller waits for its stream.  Runs on the current device.
+ * Limits (PD_E_INVALID with a message from pd_last_error(NULL) beyond them): B <=
+ * PD_STATIC_MAX_BATCH, 26 <= H, W <= PD_STATIC_MAX_SIDE; per image at most
+ * PD_STATIC_PEAKS peaks per part, PD_STATIC_PERSONS open persons and PD_STATIC_PAIRS
+ * candidate pairs (an image beyond those gets status PD_E_OVERFLOW, as with a context).
+ * Every call on a GPU uses that GPU's one array: calls that overlap on a GPU race, also
+ * across streams and threads.  The first call on a device (or any pd_create on it)
+ * looks up the array's address and must not run under stream capture. */
+#define PD_STATIC_MAX_BATCH 16
+#define PD_STATIC_MAX_SIDE 512
+#define PD_STATIC_PEAKS 64
+#define PD_STATIC_PERSONS 64
+#define PD_STATIC_PAIRS 16384
+#define PD_STATIC_SCRATCH_BYTES (4u << 20)
+int pd_decode_batch_static(const float* heat, const float* paf, int B, int h, int w, int H, int W,
+                           double thre1, double thre2, int mode, void* out, uint64_t out_capacity,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

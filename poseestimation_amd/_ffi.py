@@ -22,7 +22,8 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
-           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay', 'pd_set_host_results']
+           'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay', 'pd_set_host_results',
+           'pd_decode_batch_static']
 
 STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells', 'filter_border']
 
@@ -130,6 +131,7 @@ def lib():
     L.pd_set_graph_replay.argtypes = [vp, i32]
     L.pd_set_host_results.argtypes = [vp, i32]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.pd_decode_batch_static.argtypes = [vp, vp, i32, i32, i32, i32, i32, dbl, dbl, i32, vp, C.c_uint64, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ('pd_last_error', 'pd_version', 'pd_stream'):

@@ -9,7 +9,16 @@
 
 #pragma clang fp contract(off)
 
-static thread_local char g_err[256] = "";
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void pd_set_global_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
 
 #define PD_CHECK_CTX(ctx) \
     if ((ctx) == nullptr) return PD_E_INVALID;
@@ -81,6 +90,11 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     } while (0)
     CRH(hipSetDevice(cfg->device_id));
     CRH(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    if (pd_static_setup(cfg->device_id, ctx->err, sizeof(ctx->err)) != PD_OK) {
+        snprintf(g_err, sizeof(g_err), "%s", ctx->err);
+        pd_destroy(ctx);
+        return PD_E_HIP;
+    }
     const size_t B = cfg->max_batch, PK = cfg->max_peaks_per_part;
     CR(dev_alloc(ctx, (void**)&ctx->raw, B * PD_N_PARTS * PK * sizeof(RawPeak)));
     // counters that start every decode at zero share one allocation and one memset

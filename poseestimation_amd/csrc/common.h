@@ -197,6 +197,7 @@ struct pd_ctx {
     int have_peaks, have_conns, have_persons, packed;
     unsigned char* skel_dst;  // caller's device buffer for the skeleton copy of the results (or NULL)
     size_t skel_cap;
+    size_t res_user_cap;  // != 0: res_dev is a caller's buffer of this many bytes (the pack kernel checks it)
     int host_results;         // 0: with a skeleton buffer set, results go there only (no host mirror)
     // ---- stage timing (pd_profile) ----
     uint32_t prof_on;               // bit s set: stage s is timed
@@ -227,6 +228,11 @@ struct pd_ctx {
 // Record a start / stop event pair around a stage's kernel launch when profiling is on.
 void pd_prof_begin(pd_ctx* ctx, int stage);
 void pd_prof_end(pd_ctx* ctx);
+
+// Error text for entry points that have no context (read back with pd_last_error(NULL)).
+void pd_set_global_error(const char* fmt, ...);
+// Per-device set-up of the allocation-free entry point (address of its scratch array).
+int pd_static_setup(int device, char* err, size_t err_len);
 
 #define PD_FAIL(ctx, code, ...)                                  \
     do {                                                         \

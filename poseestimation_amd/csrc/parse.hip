@@ -633,7 +633,7 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.conn = ctx->conn;
     a.persons = ctx->persons;
     a.res = ctx->res_dev;
-    a.cap = 0;
+    a.cap = ctx->res_user_cap;
     a.lay = pd_res_layout(ctx->B);
     a.zero = ctx->zero_block;
     a.zero_words = (int)(ctx->zero_bytes / sizeof(int32_t));
