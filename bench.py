@@ -260,6 +260,7 @@ def main():
         dt = float(t.item())
 
     out = None
+    parity_failed = False
     if rank == 0:
         images = world * B * args.steps
         n, N = h * w, H * W
@@ -349,11 +350,15 @@ def main():
             out['parity_checked_images'] = ncpu
             out['parity_ok'] = bool(ok)
         print(json.dumps(out))
+        sys.stdout.flush()
+        parity_failed = out.get('parity_ok') is False
     for e in engs:
         e.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity_failed:
+        raise SystemExit('bench: the decode differs from the CPU oracle (parity_ok false)')
 
 
 if __name__ == '__main__':

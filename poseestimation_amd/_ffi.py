@@ -351,7 +351,9 @@ class Context:
         self.check(self.L.pd_flush(self._h))
 
     def sync(self):
-        """Wait for everything queued on the context's stream; raises on a decode error."""
+        """Wait for everything queued on the context's stream.  Raises on a decode error when
+        the context packs host results; a skeleton-only context (``set_host_results(False)``)
+        reports failed images through the skeleton buffer (``SkeletonGather.results`` raises)."""
         self.check(self.L.pd_sync_totals(self._h, None))
 
     def filter_stats(self):

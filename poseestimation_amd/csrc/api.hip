@@ -33,6 +33,7 @@ static int dev_alloc(pd_ctx* ctx, void** p, size_t bytes) {
 static int ensure(pd_ctx* ctx, void** p, size_t* cap, size_t bytes) {
     if (*cap >= bytes && *p) return PD_OK;
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->gen++;  // a recorded launch sequence may hold the old address
     if (*p) PD_HIP(ctx, hipFree(*p));
     *p = nullptr;
     *cap = 0;
@@ -89,12 +90,12 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
         }                                                                            \
     } while (0)
     CRH(hipSetDevice(cfg->device_id));
-    CRH(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     if (pd_static_setup(cfg->device_id, ctx->err, sizeof(ctx->err)) != PD_OK) {
         snprintf(g_err, sizeof(g_err), "%s", ctx->err);
         pd_destroy(ctx);
         return PD_E_HIP;
     }
+    CRH(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     const size_t B = cfg->max_batch, PK = cfg->max_peaks_per_part;
     CR(dev_alloc(ctx, (void**)&ctx->raw, B * PD_N_PARTS * PK * sizeof(RawPeak)));
     // counters that start every decode at zero share one allocation and one memset
@@ -579,6 +580,9 @@ extern "C" int pd_set_connections(pd_ctx* ctx, const int32_t* counts, const doub
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     if (!counts) PD_FAIL(ctx, PD_E_INVALID, "pd_set_connections: counts is NULL");
+    if (!rows)
+        for (int k = 0; k < PD_N_LIMBS; ++k)
+            if (counts[k] > 0) PD_FAIL(ctx, PD_E_INVALID, "pd_set_connections: rows is NULL but limb %d has %d connections", k, counts[k]);
     const int PK = ctx->cfg.max_peaks_per_part;
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     size_t at = 0;
@@ -727,7 +731,9 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     key.impl = ctx->impl;
     key.prof = ctx->prof_on;
     key.skel = ctx->skel_dst;
+    key.skel_cap = ctx->skel_cap;
     key.host_results = ctx->host_results;
+    key.gen = ctx->gen;
     if (ctx->graph_exec && memcmp(&key, &ctx->graph_key, sizeof(key)) == 0) {
         // the graph was recorded behind a decode that left the counters zero, so it holds no memset
         if (!ctx->zero_clean) PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));
@@ -770,6 +776,12 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     if (e_inst != hipSuccess) {
         ctx->graph_exec = nullptr;
         ctx->use_graph = 0;
+        ctx->prof_n = 0;
+        return pd_decode_fullres(ctx, thre1, thre2);
+    }
+    if (ctx->gen != key.gen) {  // something moved while recording: the sequence is already stale
+        (void)hipGraphExecDestroy(ctx->graph_exec);
+        ctx->graph_exec = nullptr;
         ctx->prof_n = 0;
         return pd_decode_fullres(ctx, thre1, thre2);
     }

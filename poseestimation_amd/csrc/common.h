@@ -96,6 +96,9 @@ struct GraphKey {
     uint32_t prof;
     int host_results;
     const void* skel;
+    uint64_t skel_cap;
+    uint64_t gen;  // pd_ctx::gen at the time: any device buffer or table a launch refers to that was
+                   // reallocated or rewritten since makes the recorded sequence stale
 };
 
 struct TableSlot {
@@ -194,10 +197,10 @@ struct pd_ctx {
     unsigned char* res_dev;
     unsigned char* res_host;
     size_t res_cap, res_spec, res_have;
+    size_t res_user_cap;  // != 0: res_dev is a caller's buffer of this many bytes (the pack kernel checks it)
     int have_peaks, have_conns, have_persons, packed;
     unsigned char* skel_dst;  // caller's device buffer for the skeleton copy of the results (or NULL)
     size_t skel_cap;
-    size_t res_user_cap;  // != 0: res_dev is a caller's buffer of this many bytes (the pack kernel checks it)
     int host_results;         // 0: with a skeleton buffer set, results go there only (no host mirror)
     // ---- stage timing (pd_profile) ----
     uint32_t prof_on;               // bit s set: stage s is timed
@@ -218,6 +221,7 @@ struct pd_ctx {
     char wk_err[512];
     // ---- HIP graph of the pd_decode_batch launch sequence ----
     int use_graph;
+    uint64_t gen;         // bumped whenever a library-owned device buffer moves or a device table is rewritten
     hipGraphExec_t graph_exec;
     GraphKey graph_key;   // what graph_exec was captured for
     GraphKey graph_seen;  // the last call that ran eagerly
@@ -225,14 +229,14 @@ struct pd_ctx {
     int graph_prof_n;
 };
 
-// Record a start / stop event pair around a stage's kernel launch when profiling is on.
-void pd_prof_begin(pd_ctx* ctx, int stage);
-void pd_prof_end(pd_ctx* ctx);
-
 // Error text for entry points that have no context (read back with pd_last_error(NULL)).
 void pd_set_global_error(const char* fmt, ...);
 // Per-device set-up of the allocation-free entry point (address of its scratch array).
 int pd_static_setup(int device, char* err, size_t err_len);
+
+// Record a start / stop event pair around a stage's kernel launch when profiling is on.
+void pd_prof_begin(pd_ctx* ctx, int stage);
+void pd_prof_end(pd_ctx* ctx);
 
 #define PD_FAIL(ctx, code, ...)                                  \
     do {                                                         \

@@ -208,7 +208,7 @@ __device__ __forceinline__ void score_six(const PairArgs& a, int b, int lane, co
         mid = pair_sample(a, b, g, i, s_up);
     }
     if (cs < 6) mid6[cs][i] = mid;
-    __builtin_amdgcn_wave_barrier();
+    pd_wave_sync();  // lane 0 of a group reads what the other nine wrote
     if (k >= 0 && i == 0) {
         // sequential sum over the ten samples, as builtin sum() does
         const double* m = mid6[cs];
@@ -222,7 +222,7 @@ __device__ __forceinline__ void score_six(const PairArgs& a, int b, int lane, co
         const double score = acc / 10.0 + geo[cs].prior;
         a.pair_score[(size_t)b * a.max_pairs + p6[cs]] = (n_above > 8 && score > 0.0) ? score : -1.0;
     }
-    __builtin_amdgcn_wave_barrier();
+    pd_wave_sync();  // mid6 is overwritten by the next six pairs
 }
 
 // Every wavefront works on its own.  The kernel is bound by the latency of the sample
@@ -274,7 +274,7 @@ k_pair_scores(PairArgs a) {
                 geo[lane] = g;
                 pq[lane] = p;
             }
-            __builtin_amdgcn_wave_barrier();  // the staging area is private to this wavefront
+            pd_wave_sync();  // the staging area is private to this wavefront; all lanes read what six wrote
             score_six(a, b, lane, s_up, geo, pq, min(PAIRS_PER_CHUNK, total - base), s_mid[wv]);
         }
         return;
@@ -303,7 +303,7 @@ k_pair_scores(PairArgs a) {
             }
             nq += __builtin_popcountll(m);
         }
-        __builtin_amdgcn_wave_barrier();
+        pd_wave_sync();
         for (int q0 = 0; q0 < nq; q0 += PAIRS_PER_CHUNK)
             score_six(a, b, lane, s_up, geo + q0, pq + q0, min(PAIRS_PER_CHUNK, nq - q0), s_mid[wv]);
     }
@@ -362,6 +362,7 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     if (ctx->src_kind == PD_SRC_LOWRES && paf_bytes > ((size_t)64 << 20)) {
         if (ctx->paf_pairs_cap < paf_bytes) {
             PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->gen++;
             if (ctx->paf_pairs) PD_HIP(ctx, hipFree(ctx->paf_pairs));
             ctx->paf_pairs = nullptr;
             ctx->paf_pairs_cap = 0;

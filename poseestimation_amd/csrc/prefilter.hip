@@ -160,6 +160,7 @@ static int build_filter_tables(pd_ctx* ctx) {
     ctx->kf_H = H;
     ctx->kf_W = W;
     ctx->kf_ok = 0;
+    ctx->gen++;  // the device tables are rewritten (and may move) below
     const int hc = (H + 7) / 8, wc = (W + 7) / 8;
     // cell coordinates are packed in 7 bits each; the active-cell kernel keeps one
     // plane (h x w) and its row sums (h x wc) in LDS
@@ -506,7 +507,7 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
                 ((float4*)wl)[2 * r] = kq[2 * r];
                 ((float4*)wl)[2 * r + 1] = kq[2 * r + 1];
             }
-            __builtin_amdgcn_wave_barrier();
+            pd_wave_sync();
         }
         // x pass: lane r < 9 owns source row y-4+r and forms the ten column sums
         if (act && r < 9) {
@@ -526,14 +527,14 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
             }
         }
         // the tile and the weights are private to this wavefront, whose LDS accesses complete in order
-        __builtin_amdgcn_wave_barrier();
+        pd_wave_sync();
         if (!REG) {
             if (act && r < 9) {
                 const float4* kq = (const float4*)(a.cy + (size_t)cur.y * 72);
                 ((float4*)wl)[2 * r] = kq[2 * r];
                 ((float4*)wl)[2 * r + 1] = kq[2 * r + 1];
             }
-            __builtin_amdgcn_wave_barrier();
+            pd_wave_sync();
         }
         // y pass: lane r owns output column 8x-1+r and forms its ten row sums
         float S[10];
@@ -557,7 +558,7 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        pd_wave_sync();
         // tolerant NMS of the cell's own 8 x 8 pixels (rows j = 1..8 of lanes r = 1..8);
         // sums of outputs outside the map are zero, like the reference's zero border
         const int X = 8 * cur.x - 1 + r;
@@ -750,6 +751,7 @@ k_verify(VerifyArgs a) {
 static int grow(pd_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
     if (*cap >= need_bytes) return PD_OK;
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->gen++;
     if (*p) PD_HIP(ctx, hipFree(*p));
     *p = nullptr;
     *cap = 0;
@@ -768,6 +770,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     if (planes_max >= (1u << 17)) return PD_E_STATE;  // plane index is packed in 17 bits
     if (!ctx->cand || ctx->cand_cap != CK) {
         PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->gen++;
         if (ctx->cand) PD_HIP(ctx, hipFree(ctx->cand));
         ctx->cand = nullptr;
         PD_HIP(ctx, hipMalloc(&ctx->cand, sizeof(int2) * planes_max * CK));

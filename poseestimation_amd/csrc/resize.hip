@@ -58,6 +58,7 @@ static int upload_tables(pd_ctx* ctx, int hs, int ws, int Hd, int Wd, double sy,
     if (slot->i && slot->key[0] == hs && slot->key[1] == ws && slot->key[2] == Hd && slot->key[3] == Wd &&
         slot->scale[0] == sy && slot->scale[1] == sx)
         return PD_OK;  // still valid
+    ctx->gen++;  // the tables of this slot are rewritten (and may move)
     if (*cap < need) {
         if (*d_i) PD_HIP(ctx, hipFree(*d_i));
         if (*d_f) PD_HIP(ctx, hipFree(*d_f));

@@ -305,6 +305,8 @@ int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
     const size_t n = (size_t)H * W;
     const size_t need = (size_t)B * PD_N_PARTS * n;
     if (ctx->tmp_smooth_cap < need) {
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->gen++;
         if (ctx->tmp_smooth) PD_HIP(ctx, hipFree(ctx->tmp_smooth));
         ctx->tmp_smooth = nullptr;
         ctx->tmp_smooth_cap = 0;
@@ -312,6 +314,8 @@ int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
         ctx->tmp_smooth_cap = need;
     }
     if (ctx->tmp_smooth2_cap < need) {
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->gen++;
         if (ctx->tmp_smooth2) PD_HIP(ctx, hipFree(ctx->tmp_smooth2));
         ctx->tmp_smooth2 = nullptr;
         ctx->tmp_smooth2_cap = 0;

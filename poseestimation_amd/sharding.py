@@ -9,7 +9,7 @@ Rank-major order of the gathered blocks is the original image order.
 """
 import numpy as np
 
-from ._ffi import CONN_DTYPE, PEAK_DTYPE, res_layout, unpack_results
+from ._ffi import CONN_DTYPE, PD_E_INDEX, PEAK_DTYPE, DecodeOverflow, res_layout, unpack_results
 
 
 def shard_range(n_images, world_size, rank):
@@ -219,6 +219,18 @@ class SkeletonGather:
                 if need:
                     raise ValueError('rank %d: its skeleton blob needs %d bytes, the gather capacity is %d'
                                      % (r, need, row.size))
-                parts.append(unpack_blob(row))
+                part = unpack_blob(row)
+                # a skeleton-only decode has no pd_sync_totals to report a failed image: the
+                # header's first_bad_image and the status table carry it across the gather
+                bad = int(np.ascontiguousarray(row[:64]).view(np.int64)[4])
+                if bad >= 0:
+                    st = int(part['status'][bad])
+                    where = 'rank %d, step slice %d, image %d of its shard' % (r, i, bad)
+                    if st == PD_E_INDEX:
+                        raise IndexError('%s: a connection touches more than two persons '
+                                         '(predict.py:199 IndexError)' % where)
+                    raise DecodeOverflow('%s: a capacity of the decode context was exceeded (status %d)'
+                                         % (where, st))
+                parts.append(part)
             out.append(concat_results(parts))
         return out

@@ -1,0 +1,169 @@
+"""Launch-graph invalidation, error reporting on the skeleton-only path, the device-resident
+hand-off against the oracle, and the result entry points that copy into caller arrays."""
+import numpy as np
+import pytest
+
+from oracle import decode_ref as ref
+from tests import golden_io as gio
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+KEYS = ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons')
+
+
+def _oracle(heat, paf, H, W, mode='D'):
+    hf = ref.resize_cubic(heat, fx=8, fy=8)[:H, :W].astype(np.float64)
+    pf = ref.resize_cubic(paf, fx=8, fy=8)[:H, :W].astype(np.float64)
+    peaks = ref.get_peaks(hf, 0.1, mode, use_scipy=True)
+    conns, special = ref.get_connections(peaks, pf, 0.05, mode)
+    return peaks, conns, special, ref.multi_person_parse(peaks, conns, special, mode)
+
+
+def test_replayed_graph_is_dropped_when_another_call_moves_buffers_or_tables():
+    """K1 three times (recorded and replayed), then K2 with a larger batch and another
+    crop height through the same context (it reallocates the staging buffers and rewrites
+    the tap and filter tables), then K1 again: every result must equal an eager context's."""
+    import torch
+    from poseestimation_amd import synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    h1, p1 = synth.batch(2, 368, 368, (2, 5), seed0=500, paf_order='xy')
+    h2, p2 = synth.batch(5, 368, 368, (2, 5), seed0=510, paf_order='xy')
+    d1 = (torch.from_numpy(h1).cuda(), torch.from_numpy(p1).cuda())
+    d2 = (torch.from_numpy(h2).cuda(), torch.from_numpy(p2).cuda())
+    eager = DecodeEngine(max_batch=5, max_h=368, max_w=368, mode='D')
+    eager.ctx.set_graph_replay(False)
+    want1 = eager.decode_batch(h1, p1, out_hw=(368, 368)).packed
+    want2 = eager.decode_batch(h2, p2, out_hw=(361, 368)).packed
+    # rows 361..367 hold peaks in K1 that K2's tables give zero weight: a stale table shows
+    assert len(want1['peaks']) > 0 and len(want2['peaks']) > 0
+    eng = DecodeEngine(max_batch=5, max_h=368, max_w=368, mode='D')
+
+    def k1():
+        eng.enqueue_device(d1[0].data_ptr(), d1[1].data_ptr(), 2, 46, 46, (368, 368))
+        return eng.fetch().packed
+
+    def k2():
+        eng.enqueue_device(d2[0].data_ptr(), d2[1].data_ptr(), 5, 46, 46, (361, 368))
+        return eng.fetch().packed
+
+    for rnd in range(2):
+        for it in range(4):
+            got = k1()
+            for key in KEYS:
+                assert np.array_equal(got[key], want1[key]), (rnd, it, key)
+        for it in range(1 + 3 * rnd):       # once eagerly; in the second round often enough to be recorded itself
+            got = k2()
+            for key in KEYS:
+                assert np.array_equal(got[key], want2[key]), (rnd, it, key)
+    got = k1()
+    for key in KEYS:
+        assert np.array_equal(got[key], want1[key]), key
+    eng.close()
+    eager.close()
+
+
+def test_graph_key_sees_the_skeleton_capacity():
+    """The same skeleton pointer with a smaller capacity must not replay the sequence that was
+    recorded for the larger one (the pack kernel checks the capacity it was launched with)."""
+    import os
+    import torch
+    from poseestimation_amd import _ffi, synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 184
+    heat, paf = synth.batch(4, H, W, (1, 4), seed0=70, paf_order='xy')
+    dh, dp = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    eng = DecodeEngine(max_batch=4, max_h=H, max_w=W, mode='D')
+    buf = torch.full((1 << 16,), 255, dtype=torch.uint8, device='cuda')
+    eng.ctx.set_skeleton_buffer(buf.data_ptr(), buf.numel())
+    eng.ctx.set_graph_replay(True)      # a context with a skeleton buffer launches eagerly unless asked
+    for _ in range(4):
+        eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), 4, 23, 23, (H, W))
+        eng.fetch()
+    small = int(_ffi.res_layout(4)[4]) + 64
+    buf.fill_(255)
+    eng.ctx.set_skeleton_buffer(buf.data_ptr(), small)
+    eng.ctx.set_graph_replay(True)
+    eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), 4, 23, 23, (H, W))
+    eng.fetch()
+    raw = buf.cpu().numpy()
+    assert int(raw[:64].view(np.int64)[5]) > small      # reported as too small ...
+    assert np.all(raw[small:] == 255)                   # ... and never overrun
+    eng.ctx.set_skeleton_buffer(None, 0)
+    eng.close()
+
+
+@pytest.mark.parametrize('caps,exc', [(dict(max_peaks_per_part=2), 'overflow'), (dict(max_persons=1), 'overflow')])
+def test_skeleton_only_decode_reports_failed_images(caps, exc):
+    """With pd_set_host_results(0) nothing is fetched from the context, so a capacity
+    overflow must surface where the skeleton buffers are read."""
+    import torch
+    from poseestimation_amd import _ffi, sharding, synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 184
+    heat, paf = synth.batch(2, H, W, 4, seed0=33, paf_order='xy')
+    dh, dp = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    full = dict(max_peaks_per_part=64, max_pairs_per_image=4000, max_persons=32)
+    full.update(caps)
+    eng = DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='D', **full)
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device='cuda')
+    eng.ctx.set_skeleton_buffer(buf.data_ptr(), buf.numel())
+    eng.ctx.set_host_results(False)
+    eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), 2, 23, 23, (H, W))
+    eng.ctx.sync()                       # only waits
+    with pytest.raises(_ffi.DecodeOverflow):
+        sharding.SkeletonGather.results(buf.cpu().numpy()[None, None])
+    eng.ctx.set_skeleton_buffer(None, 0)
+    eng.close()
+
+
+def test_device_resident_path_matches_the_oracle():
+    """Network outputs handed over as device pointers (predict.py:61 without the host round
+    trip), replayed from the recorded launch sequence: every image against the CPU oracle."""
+    import torch
+    from poseestimation_amd import synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H, W = 200, 312
+    heat, paf = synth.batch(3, H, W, (2, 5), seed0=610, paf_order='xy')
+    dh, dp = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    eng = DecodeEngine(max_batch=3, max_h=H, max_w=W, mode='D')
+    for it in range(4):                  # the fourth call is a replay
+        eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), 3, heat.shape[1], heat.shape[2], (H, W))
+        res = eng.fetch()
+    for b in range(3):
+        peaks, conns, special, subset = _oracle(heat[b], paf[b], H, W)
+        gio.assert_peaks_equal(res.all_peaks(b), peaks, exact_score=True)
+        g_conns, g_special = res.connections(b)
+        assert g_special == special
+        gio.assert_conns_equal(g_conns, conns, RTOL)
+        gio.assert_persons_equal(res.subset(b), subset, RTOL)
+    eng.close()
+
+
+def test_pd_fetch_and_pd_packed_device_agree_with_the_host_mirror():
+    import torch
+    from poseestimation_amd import _ffi, synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 184
+    heat, paf = synth.batch(3, H, W, (1, 4), seed0=90, paf_order='xy')
+    eng = DecodeEngine(max_batch=3, max_h=H, max_w=W, mode='D')
+    eng.enqueue(heat, paf)
+    a = eng.ctx.fetch()
+    b = eng.ctx.fetch_via_pd_fetch()
+    for key in KEYS + ('status',):
+        assert np.array_equal(a[key], b[key]), key
+    peaks_p, conns_p, persons_p, part_p, limb_p, pers_p = eng.ctx.packed_device()
+    import ctypes as C
+
+    def dev_bytes(ptr, n):
+        t = torch.empty(max(n, 1), dtype=torch.uint8, device='cuda')
+        hip = C.CDLL('libamdhip64.so')
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        assert hip.hipMemcpy(t.data_ptr(), ptr, n, 3) == 0     # device to device
+        return t.cpu().numpy()[:n]
+    assert dev_bytes(peaks_p, a['peaks'].nbytes).tobytes() == a['peaks'].tobytes()
+    assert dev_bytes(conns_p, a['conns'].nbytes).tobytes() == a['conns'].tobytes()
+    assert dev_bytes(persons_p, a['persons'].nbytes).tobytes() == a['persons'].tobytes()
+    assert dev_bytes(part_p, 3 * 18 * 4).view(np.int32).reshape(3, 18).tolist() == a['part_count'].tolist()
+    assert dev_bytes(pers_p, 12).view(np.int32).tolist() == a['person_count'].tolist()
+    eng.close()
