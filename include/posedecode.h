@@ -203,9 +203,13 @@ int pd_profile_read(pd_ctx* ctx, double* ms, int64_t* launches);
 int pd_debug_smoothed(pd_ctx* ctx, double* out);
 
 /* Graph replay of pd_decode_batch on device-resident inputs (on by default, off with
- * PD_NO_GRAPH=1 in the environment at pd_create).  Turn it off in processes that also run
- * a torch.distributed / RCCL process group: replaying a captured graph next to one ended
- * in GPU memory faults (ROCm 7.2, RCCL 2.26); the Python wrapper does so by itself. */
+ * PD_NO_GRAPH=1 in the environment at pd_create): a call is run eagerly the first time
+ * its arguments are seen, recorded into a HIP graph the second time and replayed from
+ * then on.  Up to eight argument sets are kept per context (least recently used goes
+ * first); whatever a recorded sequence depends on -- pointers, sizes, thresholds, mode,
+ * skeleton buffer and capacity, profiling mask, and the addresses and contents of the
+ * context's own buffers and tables -- is part of the key, so a replay never runs on
+ * stale state.  Disabling destroys the recorded sequences. */
 int pd_set_graph_replay(pd_ctx* ctx, int enable);
 
 /* pd_decode_batch on device-resident inputs, issued by a launcher thread that belongs to
@@ -227,8 +231,7 @@ int pd_flush(pd_ctx* ctx);
  * (peaks and person rows are all evaluate.py:44-74 reads).  header[5] != 0 means the
  * buffer was too small for the payload (header[5] = bytes needed); the header and the
  * count tables are always written.  NULL removes the buffer.  The buffer belongs to the
- * context's stream until the results have been waited for.  A context that was given a
- * buffer launches its kernels eagerly from then on (no graph replay).  No counterpart in the
+ * context's stream until the results have been waited for.  No counterpart in the
  * reference: the reference is single-process. */
 int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t capacity);
 

@@ -5,7 +5,6 @@ decode raises.  ctypes releases the GIL for the duration of every call.
 """
 import ctypes as C
 import os
-import sys
 
 import numpy as np
 
@@ -144,14 +143,6 @@ def _ptr(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
 
 
-def _process_group_alive():
-    td = sys.modules.get('torch.distributed')
-    try:
-        return bool(td is not None and td.is_available() and td.is_initialized())
-    except Exception:
-        return False
-
-
 class Context:
     """Owns one pd_ctx (one GPU, one HIP stream)."""
 
@@ -168,9 +159,6 @@ class Context:
         self._h = h
         self.cfg = cfg
         self.L = L
-        if _process_group_alive():
-            # graph replay next to a live process group faulted the GPU on this stack
-            self.set_graph_replay(False)
 
     def close(self):
         if self._h is not None:

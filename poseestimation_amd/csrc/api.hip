@@ -176,7 +176,8 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
         if (t.i) (void)hipFree(t.i);
         if (t.f) (void)hipFree(t.f);
     }
-    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    for (GraphSlot& g : ctx->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (ctx->res_host) (void)hipHostFree(ctx->res_host);
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
@@ -458,15 +459,25 @@ extern "C" int pd_debug_smoothed(pd_ctx* ctx, double* out) {
     return rc;
 }
 
+// Destroys every recorded launch sequence (the stream is drained first).
+static int drop_graphs(pd_ctx* ctx) {
+    bool any = false;
+    for (GraphSlot& g : ctx->graphs) any = any || g.exec != nullptr;
+    if (any) {
+        PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    for (GraphSlot& g : ctx->graphs) {
+        if (g.exec) PD_HIP(ctx, hipGraphExecDestroy(g.exec));
+        memset(&g, 0, sizeof(g));
+    }
+    return PD_OK;
+}
+
 extern "C" int pd_set_graph_replay(pd_ctx* ctx, int enable) {
     PD_CHECK_CTX(ctx);
     ctx->use_graph = enable ? 1 : 0;
-    if (!enable && ctx->graph_exec) {
-        PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
-        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        PD_HIP(ctx, hipGraphExecDestroy(ctx->graph_exec));
-        ctx->graph_exec = nullptr;
-    }
+    if (!enable) return drop_graphs(ctx);
     return PD_OK;
 }
 
@@ -479,21 +490,9 @@ extern "C" int pd_set_skeleton_buffer(pd_ctx* ctx, void* device_ptr, uint64_t ca
             PD_FAIL(ctx, PD_E_INVALID, "pd_set_skeleton_buffer: %llu bytes cannot hold the count tables of %d images (%zu bytes)",
                     (unsigned long long)capacity, ctx->cfg.max_batch, least);
     }
+    // pointer and capacity are part of the key a recorded launch sequence is replayed under
     ctx->skel_dst = (unsigned char*)device_ptr;
     ctx->skel_cap = device_ptr ? (size_t)capacity : 0;
-    if (device_ptr && ctx->use_graph) {
-        // A skeleton buffer means a multi-GPU job, i.e. a live process group in this
-        // process.  Replaying a captured launch graph next to one ended in GPU memory
-        // faults (ROCm 7.2, RCCL 2.26, first or second replay); eager launches never did.
-        // Such a context therefore launches eagerly from now on.
-        ctx->use_graph = 0;
-        if (ctx->graph_exec) {
-            PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
-            PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            PD_HIP(ctx, hipGraphExecDestroy(ctx->graph_exec));
-            ctx->graph_exec = nullptr;
-        }
-    }
     return PD_OK;
 }
 
@@ -664,6 +663,7 @@ static int prof_harvest(pd_ctx* ctx) {
             // sample and go back to eager launches, which always can
             (void)hipGetLastError();
             ctx->use_graph = 0;
+            (void)drop_graphs(ctx);
             break;
         }
         const int s = ctx->prof_stage[i];
@@ -734,33 +734,60 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     key.skel_cap = ctx->skel_cap;
     key.host_results = ctx->host_results;
     key.gen = ctx->gen;
-    if (ctx->graph_exec && memcmp(&key, &ctx->graph_key, sizeof(key)) == 0) {
-        // the graph was recorded behind a decode that left the counters zero, so it holds no memset
+    GraphSlot* slot = nullptr;
+    for (GraphSlot& g : ctx->graphs)
+        if (g.seen && memcmp(&key, &g.key, sizeof(key)) == 0) slot = &g;
+    const uint64_t now = ++ctx->graph_clock;
+    if (slot && slot->exec) {
+        // the recorded sequence holds no memset: it relies on the counters being zero
         if (!ctx->zero_clean) PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));
-        PD_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+        PD_HIP(ctx, hipGraphLaunch(slot->exec, ctx->stream));
+        slot->used = now;
         ctx->zero_clean = 1;
         ctx->have_peaks = ctx->have_conns = ctx->have_persons = 1;
         ctx->packed = skeleton_only(ctx) ? 0 : 1;
-        ctx->res_have = ctx->graph_res_have;
-        ctx->prof_n = ctx->graph_prof_n;
+        ctx->res_have = slot->res_have;
+        ctx->prof_n = slot->prof_n;
         return PD_OK;
     }
-    if (memcmp(&key, &ctx->graph_seen, sizeof(key)) != 0) {
-        // first sight of this call: run it eagerly (this also makes every lazy allocation)
-        ctx->graph_seen = key;
+    if (!slot) {
+        // first sight of this call: run it eagerly (this also makes every lazy allocation) and
+        // remember it in a free slot, else in the one that has gone unused the longest
+        GraphSlot* victim = &ctx->graphs[0];
+        for (GraphSlot& g : ctx->graphs) {
+            if (!g.seen) {
+                victim = &g;
+                break;
+            }
+            if (g.used < victim->used) victim = &g;
+        }
+        if (victim->exec) {
+            PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            PD_HIP(ctx, hipGraphExecDestroy(victim->exec));
+        }
+        memset(victim, 0, sizeof(*victim));
+        victim->key = key;
+        victim->seen = 1;
+        victim->used = now;
         return pd_decode_fullres(ctx, thre1, thre2);
     }
-    if (ctx->graph_exec) {
-        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        PD_HIP(ctx, hipGraphExecDestroy(ctx->graph_exec));
-        ctx->graph_exec = nullptr;
-    }
+    slot->used = now;
     if (ctx->prof_n > 0) {  // pairs of earlier eager calls must not be mixed into the captured set
         PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         rc = prof_harvest(ctx);
         if (rc != PD_OK) return rc;
     }
     hipGraph_t graph = nullptr;
+    // A recorded sequence must not hold a memset node: replaying one next to a live RCCL
+    // communicator ended in a GPU memory fault (ROCm 7.2; reproduced with the switch below,
+    // never without the node).  Normally the pack kernel of the previous decode has left the
+    // counters zero; if not, they are cleared in front of the recording, not inside it.
+    if (!ctx->zero_clean) {
+        PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));
+        ctx->zero_clean = 1;
+    }
+    // diagnostics only (tools/graph_pg_probe.py): record the memset node all the same
+    if (getenv("PD_DEBUG_GRAPH_MEMSET")) ctx->zero_clean = 0;
     PD_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     rc = pd_decode_fullres(ctx, thre1, thre2);
     const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
@@ -771,24 +798,24 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
         if (rc != PD_OK) return rc;
         return pd_decode_fullres(ctx, thre1, thre2);
     }
-    const hipError_t e_inst = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e_inst != hipSuccess) {
-        ctx->graph_exec = nullptr;
         ctx->use_graph = 0;
         ctx->prof_n = 0;
         return pd_decode_fullres(ctx, thre1, thre2);
     }
     if (ctx->gen != key.gen) {  // something moved while recording: the sequence is already stale
-        (void)hipGraphExecDestroy(ctx->graph_exec);
-        ctx->graph_exec = nullptr;
+        (void)hipGraphExecDestroy(exec);
+        memset(slot, 0, sizeof(*slot));
         ctx->prof_n = 0;
         return pd_decode_fullres(ctx, thre1, thre2);
     }
-    ctx->graph_key = key;
-    ctx->graph_res_have = ctx->res_have;
-    ctx->graph_prof_n = ctx->prof_n;
-    PD_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    slot->exec = exec;
+    slot->res_have = ctx->res_have;
+    slot->prof_n = ctx->prof_n;
+    PD_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
     return PD_OK;
 }
 

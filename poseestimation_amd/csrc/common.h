@@ -101,6 +101,16 @@ struct GraphKey {
                    // reallocated or rewritten since makes the recorded sequence stale
 };
 
+#define PD_GRAPH_SLOTS 8
+struct GraphSlot {
+    GraphKey key;
+    hipGraphExec_t exec;  // NULL: the key was seen once and ran eagerly
+    int seen;
+    size_t res_have;
+    int prof_n;
+    uint64_t used;        // pd_ctx::graph_clock at the last use
+};
+
 struct TableSlot {
     int32_t* i;
     float* f;
@@ -222,11 +232,11 @@ struct pd_ctx {
     // ---- HIP graph of the pd_decode_batch launch sequence ----
     int use_graph;
     uint64_t gen;         // bumped whenever a library-owned device buffer moves or a device table is rewritten
-    hipGraphExec_t graph_exec;
-    GraphKey graph_key;   // what graph_exec was captured for
-    GraphKey graph_seen;  // the last call that ran eagerly
-    size_t graph_res_have;
-    int graph_prof_n;
+    // a call is run eagerly the first time its key is seen, recorded the second time and
+    // replayed from then on; several keys are kept because a multi-GPU rank rotates its
+    // skeleton buffers (two send sets x decodes per round)
+    GraphSlot graphs[PD_GRAPH_SLOTS];
+    uint64_t graph_clock;
 };
 
 // Error text for entry points that have no context (read back with pd_last_error(NULL)).
