@@ -2,13 +2,19 @@
 """Decode throughput benchmark: network outputs (19 heatmaps + 38 PAFs at stride 8) in
 HBM -> per-person skeletons on the host, on 1..8 MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-One "step" decodes one batch of synthetic network outputs per GPU (weak scaling: the
-per-GPU batch is fixed).  For N > 1 launch under torch.distributed.run; each rank owns
-one GPU and one HIP stream, images are sharded with no data-path collective and the
-skeleton lists are gathered to rank 0 (one RCCL gather per step).  Rank 0 prints one
-JSON line.
+Workloads (the configurations of BASELINE.json):
+  b64_368           batch 64 at 368x368, single scale -- the configuration the metric is quoted on
+  b256_656          batch 256 at 656x656, ~30 people per image
+  ms4_b128_368      batch 128, four test scales (0.5, 1, 1.5, 2) averaged before the decode
+  stream_b1024_368  1024 images of 46x46x57 per step, streamed in chunks of 64 through the
+                    round pipeline (skeleton buffers gathered once per round)
+
+One "step" decodes one batch (ms4, b64, b256) or one pass of 1024 images (stream) per GPU:
+weak scaling, the per-GPU work is fixed.  For N > 1 launch under torch.distributed.run; each
+rank owns one GPU, images are sharded with no data-path collective and the skeleton lists
+are gathered to rank 0 (one RCCL gather per round of decodes).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -23,50 +29,74 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (batch per GPU, H, W, people per image, description)
-    'b64_368': (64, 368, 368, (1, 8), 'synthetic batch 64 at 368x368 (46x46x57 network output), single scale'),
-    'b256_656': (256, 656, 656, 30, 'synthetic batch 256 at 656x656, ~30 people per image'),
+    # name: batch per decode, H, W, people per image, decodes per step, default steps, description
+    'b64_368': dict(B=64, H=368, W=368, people=(1, 8), per_step=1, steps=2000, kind='single',
+                    desc='synthetic batch 64 at 368x368 (46x46x57 network output), single scale'),
+    'b256_656': dict(B=256, H=656, W=656, people=30, per_step=1, steps=300, kind='single',
+                     desc='synthetic batch 256 at 656x656, ~30 people per image'),
+    'ms4_b128_368': dict(B=128, H=368, W=368, people=(1, 8), per_step=1, steps=30, kind='multiscale',
+                         desc='synthetic batch 128 at 368x368, four test scales (0.5, 1, 1.5, 2: network outputs of '
+                              '23^2, 46^2, 69^2, 92^2 x 57) resized, averaged and decoded'),
+    'stream_b1024_368': dict(B=64, H=368, W=368, people=(1, 8), per_step=16, steps=125, kind='single',
+                             desc='1024 synthetic images of 46x46x57 per step, streamed in 16 chunks of 64 through the '
+                                  'round pipeline'),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+SCALES = (0.5, 1.0, 1.5, 2.0)
+
+
+def graph_friendly_buffers(nbuf, n_ctx, slots=6):
+    """Largest k <= nbuf such that a context used round-robin sees at most `slots` distinct
+    input buffers (a context keeps eight recorded launch sequences)."""
+    import math
+    for k in range(nbuf, 0, -1):
+        if k // math.gcd(k, n_ctx) <= slots:
+            return k
+    return 1
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--steps', type=int, default=0, help='timed steps (0: the workload\'s default)')
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='b64_368', choices=sorted(WORKLOADS))
     ap.add_argument('--mode', default='D', choices=['P', 'D'])
     ap.add_argument('--cpu-images', type=int, default=12, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the untimed extra passes (per-stage times, dense kernel, host-resident inputs)')
     ap.add_argument('--people', type=int, default=0, help='experiments: fixed people per image')
     ap.add_argument('--contexts', type=int, default=0,
-                    help='decode contexts (HIP streams) per GPU, used round-robin (0: 4 on one GPU, 3 per rank under torch.distributed)')
-    ap.add_argument('--pipeline', default='fetch', choices=['fetch', 'rounds'],
-                    help='N = 1 only.  fetch: every decode replays its launch graph and copies its full packed '
-                         'results (with the connection lists) to the host; rounds: the N > 1 pipeline with a '
-                         'plain device-to-host copy in place of the RCCL gather (peaks + person rows per round '
-                         'of decodes, eager launches from the contexts\' launcher threads)')
+                    help='decode contexts (HIP streams) per GPU, used round-robin (0: 4; 1 for the multi-scale workload, whose kernels fill the chip by themselves)')
+    ap.add_argument('--pipeline', default='', choices=['', 'fetch', 'rounds'],
+                    help='N = 1 only.  fetch: every decode copies its full packed results (with the connection '
+                         'lists) to the host; rounds: the N > 1 pipeline with a plain device-to-host copy in place of '
+                         'the RCCL gather (peaks + person rows per round of decodes, issued by the contexts\' '
+                         'launcher threads).  Default: fetch, rounds for the stream workload')
     ap.add_argument('--hw-queues', type=int, default=-1,
                     help='GPU_MAX_HW_QUEUES for this process when the environment asks for fewer '
-                         '(0: leave it; -1: 8 on one GPU, left alone under torch.distributed)')
+                         '(0: leave it; -1: 8 on one GPU with the fetch pipeline, left alone otherwise)')
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    if args.steps <= 0:
+        args.steps = wl['steps']
     world = int(os.environ.get('WORLD_SIZE', '1'))
     # PD_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL gather of the skeleton buffers)
     # with a single rank, which is how that path is rehearsed on a one-GPU box
     use_dist = world > 1 or os.environ.get('PD_BENCH_FORCE_DIST') == '1'
-    rounds = use_dist or args.pipeline == 'rounds'
+    multiscale = wl['kind'] == 'multiscale'
+    if not args.pipeline:
+        args.pipeline = 'rounds' if wl['per_step'] > 1 else 'fetch'
+    rounds = (use_dist or args.pipeline == 'rounds') and not multiscale
     if args.contexts <= 0:
-        args.contexts = 4
+        args.contexts = 1 if multiscale else 4
     if args.hw_queues < 0:
-        # measured: replayed graphs want a queue per context (4 contexts: 8 queues), the eager
-        # launches of the round pipeline lose throughput with more than the default 4
-        args.hw_queues = 0 if rounds else 8
+        args.hw_queues = 0 if (rounds or multiscale) else 8
 
     # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default);
     # streams that share a queue run one behind the other.  Every decode context needs a
-    # queue of its own next to the one torch uses, so raise the count before HIP starts
-    # (replayed launch graphs: four contexts on eight queues decode 12 % more than three on four).
+    # queue of its own next to the one torch uses, so raise the count before HIP starts.
     try:
         have_q = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
     except ValueError:
@@ -75,8 +105,6 @@ def main():
         os.environ['GPU_MAX_HW_QUEUES'] = str(args.hw_queues)
     import torch
     import torch.distributed as dist
-    from poseestimation_amd import _ffi, sharding, synth
-    from poseestimation_amd.predict_decode import DecodeEngine, Results
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -103,30 +131,92 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    B, H, W, people, desc = WORKLOADS[args.workload]
+    env = dict(args=args, wl=wl, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist, rounds=rounds,
+               torch=torch, dist=dist)
+    out = run_multiscale(env) if multiscale else run_single(env)
+    parity_failed = False
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+        parity_failed = out.get('parity_ok') is False
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit('bench: the decode differs from the CPU oracle (parity_ok false)')
+
+
+def make_barrier(env):
+    torch, dist = env['torch'], env['dist']
+
+    def barrier():
+        torch.cuda.synchronize()         # device-wide: covers the contexts' own streams
+        if env['use_dist']:
+            dist.barrier()
+        torch.cuda.synchronize()
+    return barrier
+
+
+def max_over_ranks(env, dt):
+    if not env['use_dist']:
+        return dt
+    torch, dist = env['torch'], env['dist']
+    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def pmc_traffic(workload):
+    """Counter-derived HBM bytes per launch, committed under profiles/ by tools/summarize_profile.py."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % workload)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------------------------------------
+# single-scale workloads: b64_368, b256_656, stream_b1024_368
+# ---------------------------------------------------------------------------------------------
+def run_single(env):
+    args, wl, world, rank, torch = env['args'], env['wl'], env['world'], env['rank'], env['torch']
+    use_dist, rounds = env['use_dist'], env['rounds']
+    from poseestimation_amd import _ffi, sharding, synth
+    from poseestimation_amd.predict_decode import DecodeEngine, Results
+
+    B, H, W, people = wl['B'], wl['H'], wl['W'], wl['people']
+    desc = wl['desc']
     if args.people:      # experiments only: a fixed number of people per image
         people = args.people
         desc += ' (people per image overridden: %d)' % people
     h, w = H // 8, W // 8
     heat, paf = synth.batch(B, H, W, people, seed0=rank * B, paf_order='xy' if args.mode == 'D' else 'yx')
-    d_heat = torch.from_numpy(heat).cuda()
-    d_paf = torch.from_numpy(paf).cuda()
+    # Distinct input buffers, used in turn, so that no step finds its inputs in the caches left
+    # by the step before (together they exceed the 256 MiB Infinity Cache at 368^2): buffer k
+    # holds the batch rotated by k images, i.e. image b of buffer k is image (b + k) % B.
+    GATHER_DEPTH = 2   # decodes per context between two gathers
+    n_ctx = args.contexts
+    per_step = wl['per_step']
+    if rounds:
+        NBUF = n_ctx * GATHER_DEPTH * (2 if per_step > 1 else 1)   # one buffer per slice of a round (or of two)
+    else:
+        NBUF = 12 if B * h * w * 57 * 4 < (64 << 20) else 4
+        NBUF = graph_friendly_buffers(NBUF, n_ctx)
+    d_heat = [torch.from_numpy(np.roll(heat, -k, axis=0)).cuda() for k in range(NBUF)]
+    d_paf = [torch.from_numpy(np.roll(paf, -k, axis=0)).cuda() for k in range(NBUF)]
     torch.cuda.synchronize()
 
     # several contexts (one HIP stream each) used round-robin: while the skeletons of
     # batch i are copied out and gathered, the kernels of the next batches already run,
     # and the short kernels of different batches overlap on the chip
-    engs = [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=local_rank,
+    engs = [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=env['local_rank'],
                          max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000)
-            for _ in range(args.contexts)]
+            for _ in range(n_ctx)]
     eng = engs[0]
-    gather_cap = 1 << 18      # per rank and step: header, count tables, peaks, person rows
+    gather_cap = 1 << 18      # per rank and decode: header, count tables, peaks, person rows
     while gather_cap < B * 4096:
         gather_cap <<= 1
 
-    # (contexts that are given a skeleton buffer launch eagerly: graph replay next to a live
-    # process group faulted on this stack, see pd_set_skeleton_buffer)
-    GATHER_DEPTH = 2   # decodes per context between two gathers
     gather = gather1 = None
     if rounds:
         gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap, depth=GATHER_DEPTH, local=not use_dist)
@@ -135,25 +225,31 @@ def main():
             e.ctx.set_host_results(False)
 
     host_t = [0.0, 0.0, 0.0, 0.0, 0]   # finish, submit, flush, start, rounds
+    counter = [0]                      # decodes issued so far: picks the input buffer
 
-    def run(nsteps, pool=None):
-        """nsteps steps = nsteps batches decoded and their skeletons brought to the host
-        (N = 1: the packed results of the batch; N > 1: every rank's peaks and person
-        rows gathered to rank 0 over RCCL)."""
-        n, last = len(engs), None
+    def run(ndecodes, pool=None):
+        """ndecodes batches decoded and their skeletons brought to the host (fetch: the packed
+        results of every batch; rounds: peaks and person rows of a round of decodes in one
+        copy, or -- N > 1 -- gathered to rank 0 over RCCL).  Returns (results, buffer) of the
+        last decode."""
         pool_arg = pool
         if gather is None:
             pool = pool or engs
             n = len(pool)
-            pending = []
-            for i in range(nsteps):
+            nbuf = graph_friendly_buffers(NBUF, n)
+            pending, last = [], None
+            for i in range(ndecodes):
                 e = pool[i % n]
                 if len(pending) == n:
-                    last = pending.pop(0).ctx.fetch()   # waits for that stream; results now on the host
-                e.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, (H, W))
-                pending.append(e)
+                    pe, pk = pending.pop(0)
+                    last = (pe.ctx.fetch(), pk)     # waits for that stream; results now on the host
+                k = counter[0] % nbuf
+                counter[0] += 1
+                e.enqueue_device(d_heat[k].data_ptr(), d_paf[k].data_ptr(), B, h, w, (H, W))
+                pending.append((e, k))
             while pending:
-                last = pending.pop(0).ctx.fetch()
+                pe, pk = pending.pop(0)
+                last = (pe.ctx.fetch(), pk)
             return last
         # rounds of GATHER_DEPTH decodes per context; the gather of round r (set r % 2 of the
         # send buffers) is in flight while round r + 1 decodes; the host never waits for a decode
@@ -162,18 +258,22 @@ def main():
             g, pool = gather1, pool_arg
         n = len(pool)
         last, r, done = None, 0, 0
-        pending = [False, False]
-        while done < nsteps:
+        pending = [None, None]
+        while done < ndecodes:
             s = r % 2
             ta = time.perf_counter()
-            if pending[s]:
+            if pending[s] is not None:
                 rows = g.finish(s)
-                last = rows if rows is not None else last
+                if rows is not None:
+                    last = (rows, pending[s])
             tb = time.perf_counter()
-            k = min(n * GATHER_DEPTH, nsteps - done)
-            # the contexts' launcher threads issue the (eager) kernel launches in parallel
+            k = min(n * GATHER_DEPTH, ndecodes - done)
+            bufs = []
+            # the contexts' launcher threads issue the launches (or graph replays) in parallel
             for j in range(k):
-                pool[j % n].ctx.submit(d_heat.data_ptr(), d_paf.data_ptr(), B, h, w, H, W, 0.1, 0.05,
+                kb = (s * n * GATHER_DEPTH + j) % NBUF if per_step > 1 else j % NBUF
+                bufs.append(kb)
+                pool[j % n].ctx.submit(d_heat[kb].data_ptr(), d_paf[kb].data_ptr(), B, h, w, H, W, 0.1, 0.05,
                                        g.slice_ptr(s, j), g.capacity)
             tc = time.perf_counter()
             for e in pool:
@@ -186,25 +286,21 @@ def main():
             host_t[2] += td - tc
             host_t[3] += te - td
             host_t[4] += 1
-            pending[s] = True
+            pending[s] = bufs
             done += k
             r += 1
         for s in (r % 2, (r + 1) % 2):
-            if pending[s]:
+            if pending[s] is not None:
                 rows = g.finish(s)
-                last = rows if rows is not None else last
+                if rows is not None:
+                    last = (rows, pending[s])
         return last
 
-    def barrier():
-        torch.cuda.synchronize()         # device-wide: covers the contexts' own streams
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Timed region: only the roofline kernel carries an event pair (one pair per step);
-    # timing every kernel would put two dozen event records between the kernels of
-    # every step and slow the job down by a third.  The full per-stage breakdown comes
-    # from a separate, untimed pass afterwards.
+    barrier = make_barrier(env)
+    # Timed region: only one stage carries an event pair (one pair per decode); timing every
+    # kernel would put two dozen event records between the kernels of every decode and slow
+    # the job down by a third.  The full per-stage breakdown comes from a separate, untimed
+    # pass afterwards.
     ROOF_STAGE = 'filter'
     # Python's cyclic collector walks every object the imports left behind (torch, numpy) at its
     # first full pass: a 35 ms stop some 650 steps into the run.  Those objects are parked in
@@ -214,16 +310,17 @@ def main():
     gc.freeze()
     for e in engs:
         e.ctx.profile(stages=[ROOF_STAGE])
-    # every context reaches its captured launch graph (third identical call); with a process
-    # group, the first gathers also set up RCCL's channels and the launcher threads
-    run(3 * len(engs) if gather is None else 8 * len(engs) * GATHER_DEPTH)
-    last = run(args.warmup)
+    # every context reaches its recorded launch sequences (third identical call per input
+    # buffer and skeleton slice); with a process group, the first gathers also set up RCCL's
+    # channels and the launcher threads
+    run(3 * max(NBUF, len(engs) * GATHER_DEPTH * 2) if gather is None else 8 * len(engs) * GATHER_DEPTH)
+    run(args.warmup * per_step)
     for e in engs:
         e.ctx.profile_read()
     barrier()
     host_t[:] = [0.0, 0.0, 0.0, 0.0, 0]
     t0 = time.perf_counter()
-    last = run(args.steps)
+    last = run(args.steps * per_step)
     barrier()
     dt = time.perf_counter() - t0
     if os.environ.get('PD_BENCH_TIMERS') == '1' and host_t[4]:
@@ -234,98 +331,157 @@ def main():
         v = e.ctx.profile_read()[ROOF_STAGE]
         roof_ms += v[0]
         roof_n += v[1]
-    # the same event pair with one context decoding alone: the kernel's own duration, which is
-    # what a kernel trace (rocprofv3 serialises the kernels of all streams) reports; in the
-    # timed region the kernel shares the chip with the kernels of the other contexts' decodes
-    alone_ms, alone_n = 0.0, 0
-    if not use_dist:
-        run(min(100, args.steps), pool=engs[:1])
-        alone_ms, alone_n = engs[0].ctx.profile_read()[ROOF_STAGE]
-    prof = {}
-    stage_steps = max(10, min(50, args.steps))
-    for e in engs:
-        e.ctx.profile(True)
-    run(3 * len(engs))
-    for e in engs:
-        e.ctx.profile_read()
-    run(stage_steps)
-    for e in engs:
-        for k, v in e.ctx.profile_read().items():
-            a = prof.get(k, (0.0, 0))
-            prof[k] = (a[0] + v[0], a[1] + v[1])
-        e.ctx.profile(False)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(env, dt)
+
+    # ---- untimed extra passes (rank 0 of a single-GPU run only) ----
+    extras = rank == 0 and not use_dist and not args.no_extras
+    prof, alone, dense_ms, host_rate = {}, None, None, None
+    if extras:
+        # the same event pair with one context decoding alone: the kernel's own duration, which is
+        # what a kernel trace (rocprofv3 serialises the kernels of all streams) reports
+        run(min(100, args.steps * per_step), pool=engs[:1])
+        alone = engs[0].ctx.profile_read()[ROOF_STAGE]
+        stage_decodes = max(10, min(50, args.steps * per_step))
+        for e in engs:
+            e.ctx.profile(True)
+        run(3 * NBUF if gather is None else 8 * len(engs) * GATHER_DEPTH)
+        for e in engs:
+            e.ctx.profile_read()
+        run(stage_decodes)
+        for e in engs:
+            for k, v in e.ctx.profile_read().items():
+                a = prof.get(k, (0.0, 0))
+                prof[k] = (a[0] + v[0], a[1] + v[1])
+            e.ctx.profile(False)
+        # the exact float64 kernel over every pixel (PD_IMPL_STREAM): the kernel that does the
+        # work the byte formula of the peak stage prices (upsample, Gaussian, NMS on every pixel)
+        dctx = _ffi.Context(device_id=env['local_rank'], max_batch=B, max_h=H, max_w=W, max_peaks_per_part=128,
+                            max_persons=128, max_pairs_per_image=40000)
+        dctx.set_mode(_ffi.MODE_D if args.mode == 'D' else _ffi.MODE_P)
+        dctx.set_impl(_ffi.IMPL_STREAM)
+        dctx.set_graph_replay(False)
+        dctx.profile(stages=['smooth_nms'])
+        for i in range(6):
+            dctx.set_lowres(d_heat[0].data_ptr(), d_paf[0].data_ptr(), B, h, w, H, W, _ffi.MEM_DEVICE)
+            dctx.peaks(0.1)
+            if i == 1:
+                dctx.profile_read()
+        v = dctx.profile_read()['smooth_nms']
+        dense_ms = v[0] / max(v[1], 1)
+        dctx.close()
+        # inputs handed over as host arrays (pinned): the reference's own boundary, predict.py:61
+        if gather is None:
+            ph = torch.from_numpy(heat).pin_memory()
+            pp = torch.from_numpy(paf).pin_memory()
+            nh = max(8, min(200, args.steps))
+            pend = []
+
+            def host_pass(count):
+                for i in range(count):
+                    e = engs[i % len(engs)]
+                    if len(pend) == len(engs):
+                        pend.pop(0).ctx.fetch()
+                    e.enqueue(ph.numpy(), pp.numpy(), (H, W))
+                    pend.append(e)
+                while pend:
+                    pend.pop(0).ctx.fetch()
+            host_pass(2 * len(engs))
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            host_pass(nh)
+            torch.cuda.synchronize()
+            host_rate = nh * B / (time.perf_counter() - th)
 
     out = None
-    parity_failed = False
     if rank == 0:
-        images = world * B * args.steps
+        images = world * B * per_step * args.steps
         n, N = h * w, H * W
-        # Roofline kernel: k_cell_filter, the float32 evaluation of the smoothed x8 map
-        # and its non-maximum suppression (with k_cells, which picks the 8x8 cells it has
-        # to visit, it stands for the reference's upsample + Gaussian + NMS pass over every
-        # pixel of the 18 part channels).  Algorithmic bytes per image of that pass:
-        # upsample read 18*n*4 + write 18*N*4, Gaussian read + write 2*18*N*4, NMS read
-        # 18*N*4  =  72*n + 288*N.  The kernel itself touches a few percent of that, so the
-        # fraction says how much faster than a materialising implementation at HBM peak
-        # the stage runs, not how busy HBM is.
-        kname = 'k_cell_filter'
-        sm_ms, sm_n = roof_ms, roof_n
-        if sm_n == 0:       # the exact streaming kernel ran alone (no filter tables for this geometry)
-            kname = 'k_smooth_nms_stream'
-            sm_ms, sm_n = prof['smooth_nms']
-        alg_bytes = B * (72.0 * n + 288.0 * N)
-        avg_s = (sm_ms / max(sm_n, 1)) * 1e-3
-        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.workload)
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                traffic = json.load(f).get('roofline_kernel_hbm_bytes_per_launch')
-        # the whole decode against the whole-path byte count per image:
-        # 228*n + 228*N + 216*N (+ 80 bytes per candidate pair, not counted here)
-        job_bytes = 228.0 * n + 444.0 * N
         value = images / dt
+        step_s = dt / args.steps
+        rows, bufs = last
+        if gather is None:
+            res0, buf0 = rows, bufs
+        else:
+            allres = sharding.SkeletonGather.results(rows)
+            res0, buf0 = allres[0], bufs[0]
+        # Bytes one decode has to move for this algorithm: the network output read once, the
+        # packed results written once.  (The survey's per-image formula prices an implementation
+        # that materialises the x8 maps; this path never forms them -- see `dense_path`.)
+        result_bytes = int(len(res0['raw'])) if 'raw' in res0 else int(res0['peaks'].nbytes + res0['persons'].nbytes)
+        must_bytes = B * n * 57 * 4.0 + result_bytes
+        decode_s = step_s / per_step
+        pmc = pmc_traffic(args.workload if args.workload != 'stream_b1024_368' else 'b64_368')
+        step_traffic = pmc.get('step_hbm_bytes') if pmc else None
+        roofline = {
+            'bound': 'hbm', 'kernel': 'whole decode of one batch (all kernels of the chain, %d contexts overlapped)' % len(engs),
+            'achieved': must_bytes / decode_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': must_bytes / decode_s / 1e9 / HBM_PEAK_GBS,
+            'traffic': step_traffic,
+            'algorithmic_bytes_per_launch': must_bytes,
+            'bytes_counted': 'network output of the batch read once (B*h*w*57*4) + packed results written once',
+            'avg_launch_ms': decode_s * 1e3,
+            'note': 'the fused path is bound by launch latency and vector-ALU issue, not by HBM: its kernels '
+                    'visit only the few percent of the full-resolution map that can hold a peak',
+        }
+        if step_traffic:
+            roofline['wasted_traffic_ratio'] = step_traffic / must_bytes
+        if roof_n:
+            f_s = roof_ms / roof_n * 1e-3
+            kt = None
+            if pmc and pmc.get('kernels'):
+                for kname, kv in pmc['kernels'].items():
+                    if kname.startswith('k_cell_filter'):
+                        kt = kv['hbm_bytes']
+            roofline['k_cell_filter'] = {
+                'avg_launch_ms': f_s * 1e3, 'launches': roof_n,
+                'measured': 'HIP event pair around the kernel in every decode of the timed region',
+                'traffic': kt, 'achieved': (kt / f_s / 1e9) if kt else None,
+                'frac': (kt / f_s / 1e9 / HBM_PEAK_GBS) if kt else None,
+                'bound': 'valu issue + latency (profiles/*sq_counters*)'}
+            if alone and alone[1]:
+                roofline['k_cell_filter']['one_context_avg_launch_ms'] = alone[0] / alone[1]
+        if dense_ms:
+            dense_bytes = B * (72.0 * n + 288.0 * N)
+            peak_stage_ms = sum(prof[k][0] / prof[k][1] for k in ('planar', 'cells', 'filter', 'verify', 'smooth_nms')
+                                if k in prof and prof[k][1])
+            roofline['dense_path'] = {
+                'kernel': 'k_smooth_nms_stream (PD_IMPL_STREAM: exact float64 kernel over every pixel)',
+                'algorithmic_bytes_per_launch': dense_bytes,
+                'bytes_counted': 'x8 upsample of 18 channels read + write, Gaussian read + write, NMS read: B*(72*n + 288*N)',
+                'avg_launch_ms': dense_ms, 'achieved': dense_bytes / (dense_ms * 1e-3) / 1e9,
+                'frac': dense_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'sparse_peak_stage_ms': peak_stage_ms,
+                'dense_equivalent_speedup': (dense_bytes / (HBM_PEAK_GBS * 1e9) * 1e3) / peak_stage_ms if peak_stage_ms else None,
+                'note': 'dense_equivalent_speedup = time a materialising pass would need at HBM peak / time of the '
+                        'sparse peak stage (layout copy + cell scan + cell filter + verification)'}
         out = {
             'metric': 'decoded images/sec (heatmap+PAF->skeletons) at %dx%d' % (H, W),
             'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': desc, 'batch_per_gpu': B, 'mode': args.mode,
+            'config': {'workload': desc, 'name': args.workload, 'batch_per_gpu': B * per_step, 'mode': args.mode,
                        'contexts_per_gpu': len(engs), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
                        'people_per_image': list(people) if isinstance(people, tuple) else people,
-                       'outputs': 'full packed results (peaks, connection lists, person rows) copied to the host every step'
+                       'inputs': 'device-resident network outputs, %d distinct batches of %.1f MB used in turn '
+                                 '(the host-to-device copy of predict.py:61 is outside the timed region; '
+                                 'see host_inputs_images_per_s)' % (NBUF, B * n * 57 * 4 / 1e6),
+                       'outputs': 'full packed results (peaks, connection lists, person rows) copied to the host every decode'
                                   if gather is None else
                                   'peaks and person rows copied to the host once per round of %d decodes' % gather.n
                                   if not use_dist else
                                   'peaks and person rows of every rank gathered to rank 0 (RCCL) and copied to its host, '
                                   'once per round of %d decodes per rank' % gather.n},
-            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': sm_n,
-                         'algorithmic_bytes_per_launch': alg_bytes,
-                         'measured': 'HIP event pair around the kernel in every step of the timed region, '
-                                     '%d decodes in flight on the chip' % len(engs),
-                         'note': 'algorithmic bytes are those of the reference\'s materialising upsample + Gaussian + NMS '
-                                 'pass, which this kernel replaces on the few percent of the map that can hold a peak: '
-                                 'frac > 1 means faster than that pass could run at HBM peak; the kernel itself is '
-                                 'bound by vector-ALU issue (profiles/*sq_counters*), its HBM traffic is `traffic`'},
-            'job_hbm_frac_per_gpu': (value / world) * job_bytes / 1e9 / HBM_PEAK_GBS,
-            'stage_ms_per_launch_untimed_pass': {k: v[0] / v[1] for k, v in prof.items() if v[1]},
+            'roofline': roofline,
         }
-        if alone_n and kname == 'k_cell_filter':
-            a_s = alone_ms / alone_n * 1e-3
-            out['roofline']['one_context'] = {
-                'avg_launch_ms': a_s * 1e3, 'launches': alone_n, 'achieved': alg_bytes / a_s / 1e9,
-                'frac': alg_bytes / a_s / 1e9 / HBM_PEAK_GBS,
-                'measured': 'same event pair, one context decoding alone after the timed region '
-                            '(comparable with a kernel trace, which serialises kernels)'}
-        res0 = last if gather is None else sharding.SkeletonGather.results(last)[0]
+        if prof:
+            out['stage_ms_per_launch_untimed_pass'] = {k: v[0] / v[1] for k, v in prof.items() if v[1]}
+        if host_rate:
+            out['host_inputs_images_per_s'] = host_rate
+            out['host_inputs_note'] = 'same decode with the network outputs in pinned host memory (PD_MEM_HOST): ' \
+                                      'the copy over PCIe is inside this rate'
         out['persons_last_step'] = int(res0['person_count'].sum())
-        out['filter_stats_last_step'] = eng.ctx.filter_stats()
+        if gather is None:
+            out['filter_stats_last_step'] = eng.ctx.filter_stats()
 
         if not use_dist and not args.no_cpu:
             from oracle import decode_ref as ref
@@ -334,8 +490,9 @@ def main():
             tc = time.perf_counter()
             ok = True
             for b in range(ncpu):
-                hf = ref.resize_cubic(heat[b], fx=8, fy=8).astype(np.float64)
-                pf = ref.resize_cubic(paf[b], fx=8, fy=8).astype(np.float64)
+                src = (b + buf0) % B
+                hf = ref.resize_cubic(heat[src], fx=8, fy=8).astype(np.float64)
+                pf = ref.resize_cubic(paf[src], fx=8, fy=8).astype(np.float64)
                 peaks = ref.get_peaks(hf, 0.1, args.mode, use_scipy=True)
                 conns, special = ref.get_connections(peaks, pf, 0.05, args.mode)
                 subset = ref.multi_person_parse(peaks, conns, special, args.mode)
@@ -344,21 +501,169 @@ def main():
                     and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0)
             tcpu = time.perf_counter() - tc
             out['cpu_baseline'] = {'value': ncpu / tcpu, 'unit': 'images/s', 'cores': 1, 'kind': 'port',
-                                   'sample': 'first %d images of the same batch through oracle/decode_ref.py '
+                                   'sample': '%d images of the same batch through oracle/decode_ref.py '
                                              '(numpy bicubic + scipy gaussian_filter + numpy decode), one thread; '
                                              'host has %d cpus' % (ncpu, os.cpu_count())}
             out['parity_checked_images'] = ncpu
             out['parity_ok'] = bool(ok)
-        print(json.dumps(out))
-        sys.stdout.flush()
-        parity_failed = out.get('parity_ok') is False
     for e in engs:
         e.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0 and parity_failed:
-        raise SystemExit('bench: the decode differs from the CPU oracle (parity_ok false)')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-scale workload: ms4_b128_368  (predict.py:49-72, then the decode)
+# ---------------------------------------------------------------------------------------------
+def run_multiscale(env):
+    args, wl, world, rank, torch = env['args'], env['wl'], env['world'], env['rank'], env['torch']
+    from poseestimation_amd import synth
+    from poseestimation_amd.predict_decode import DecodeEngine, Results
+
+    B, H, W, people = wl['B'], wl['H'], wl['W'], wl['people']
+    # 32 distinct scenes per rank, each rendered at the four test scales, repeated to the batch
+    NSCENE = min(32, B)
+    rng = np.random.RandomState(100003 + rank)
+    counts = [int(rng.randint(people[0], people[1] + 1)) for _ in range(NSCENE)]
+    heats, pafs = [], []
+    for s in SCALES:
+        outs = [synth.scene(H, W, counts[i], 7000 + rank * NSCENE + i, paf_order='xy' if args.mode == 'D' else 'yx', scale=s)
+                for i in range(NSCENE)]
+        heats.append(np.stack([outs[b % NSCENE][0] for b in range(B)]))
+        pafs.append(np.stack([outs[b % NSCENE][1] for b in range(B)]))
+    sizes = [(a.shape[1], a.shape[2]) for a in heats]
+    crops = [(8 * hs, 8 * ws) for hs, ws in sizes]          # 368 * scale is a multiple of 8: no padding to remove
+    d_heats = [torch.from_numpy(a).cuda() for a in heats]
+    d_pafs = [torch.from_numpy(a).cuda() for a in pafs]
+    torch.cuda.synchronize()
+    engs = [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=env['local_rank'],
+                         max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000, fullres=True)
+            for _ in range(args.contexts)]
+    hp = [t.data_ptr() for t in d_heats]
+    pp = [t.data_ptr() for t in d_pafs]
+
+    def run(nsteps):
+        pending, last = [], None
+        for i in range(nsteps):
+            e = engs[i % len(engs)]
+            if len(pending) == len(engs):
+                last = pending.pop(0).ctx.fetch()
+            e.ctx.upsample_avg_device(hp, pp, sizes, crops, H, W, B)
+            e.ctx.decode_fullres(0.1, 0.05)
+            pending.append(e)
+        while pending:
+            last = pending.pop(0).ctx.fetch()
+        return last
+
+    barrier = make_barrier(env)
+    import gc
+    gc.collect()
+    gc.freeze()
+    TIMED = ['resize', 'smooth_nms', 'filter', 'verify']
+    for e in engs:
+        e.ctx.profile(stages=TIMED)
+    run(2 * len(engs))
+    run(min(args.warmup, 4))
+    for e in engs:
+        e.ctx.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    last = run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    stage = {}
+    for e in engs:
+        for k, v in e.ctx.profile_read().items():
+            a = stage.get(k, (0.0, 0))
+            stage[k] = (a[0] + v[0], a[1] + v[1])
+    dt = max_over_ranks(env, dt)
+    prof = {}
+    if rank == 0 and not env['use_dist'] and not args.no_extras:
+        for e in engs:
+            e.ctx.profile(True)
+        run(len(engs))
+        for e in engs:
+            e.ctx.profile_read()
+        run(2 * len(engs))
+        for e in engs:
+            for k, v in e.ctx.profile_read().items():
+                a = prof.get(k, (0.0, 0))
+                prof[k] = (a[0] + v[0], a[1] + v[1])
+            e.ctx.profile(False)
+
+    out = None
+    if rank == 0:
+        value = world * B * args.steps / dt
+        n_sum = sum(hs * ws for hs, ws in sizes)
+        N_sum = 64 * n_sum
+        N = H * W
+        # The resize stage (x8 upsample, second resize and average of all scales, heat and PAF
+        # families): kernel time summed over its launches of one step.
+        resize_ms = stage['resize'][0] / max(args.steps, 1)
+        resize_launches = stage['resize'][1] / max(args.steps, 1)
+        must = B * (228.0 * n_sum + 57.0 * N * 8)                          # network outputs read, float64 averages written
+        survey = B * (228.0 * n_sum + 2 * 228.0 * N_sum + 57.0 * N * 8)    # + the four x8 maps written and read back
+        pmc = pmc_traffic(args.workload)
+        traffic = pmc.get('resize_stage_hbm_bytes') if pmc else None
+        roofline = {
+            'bound': 'hbm', 'kernel': 'resize stage of one step: x8 bicubic + second resize + average of four scales, '
+                                      '%.0f launches (k_resize_*)' % resize_launches,
+            'achieved': must / (resize_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': must / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'traffic': traffic,
+            'algorithmic_bytes_per_launch': must,
+            'bytes_counted': 'B * (228 * sum_s n_s  +  57 * N * 8): every network output read once, the float64 '
+                             'averages written once',
+            'avg_launch_ms': resize_ms,
+            'measured': 'HIP event pairs around the stage\'s kernels in every step of the timed region',
+            'survey_formula_bytes': survey,
+            'survey_formula_note': 'the survey\'s per-image formula also counts the four x8 maps written and read back '
+                                   '(2 * 228 * sum_s N_s); an implementation that materialises them moves that much',
+        }
+        sf = survey / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roofline['survey_formula_frac'] = sf if sf <= 1.0 else None
+        roofline['survey_formula_speedup_vs_hbm_peak'] = sf
+        if traffic:
+            roofline['traffic_frac'] = traffic / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roofline['wasted_traffic_ratio'] = traffic / must
+        out = {
+            'metric': 'decoded images/sec (heatmap+PAF->skeletons) at %dx%d' % (H, W),
+            'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': wl['desc'], 'name': args.workload, 'batch_per_gpu': B, 'mode': args.mode,
+                       'contexts_per_gpu': len(engs), 'scales': list(SCALES),
+                       'inputs': 'device-resident network outputs of the four scales (%.0f MB per step; %d distinct '
+                                 'scenes repeated to the batch)' % (B * 228.0 * n_sum / 1e6, NSCENE),
+                       'outputs': 'full packed results copied to the host every step'},
+            'roofline': roofline,
+            'stage_ms_per_step_timed_region': {k: v[0] / args.steps for k, v in stage.items() if v[1]},
+        }
+        if prof:
+            out['stage_ms_per_launch_untimed_pass'] = {k: v[0] / v[1] for k, v in prof.items() if v[1]}
+        out['persons_last_step'] = int(last['person_count'].sum())
+        if not env['use_dist'] and not args.no_cpu:
+            from oracle import decode_ref as ref
+            ncpu = max(1, min(args.cpu_images // 4, 3))
+            r = Results(last, engs[0].mode)
+            ok = True
+            tc = time.perf_counter()
+            for b in range(ncpu):
+                want_h, want_p = ref.upsample_average([a[b] for a in heats], [a[b] for a in pafs], [(0, 0)] * 4, (H, W))
+                cand, peaks, subset = ref.decode(want_h, want_p, 0.1, 0.05, args.mode)
+                g = r.subset(b)
+                ok = ok and g.shape == subset.shape and np.array_equal(g[:, :18], subset[:, :18]) \
+                    and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0) \
+                    and np.array_equal(r.candidate(b)[:, :2], cand[:, :2])
+            tcpu = time.perf_counter() - tc
+            out['cpu_baseline'] = {'value': ncpu / tcpu, 'unit': 'images/s', 'cores': 1, 'kind': 'port',
+                                   'sample': '%d images of the same batch through oracle/decode_ref.py (four-scale numpy '
+                                             'bicubic + average, restated gaussian_filter, numpy decode), one thread; '
+                                             'host has %d cpus' % (ncpu, os.cpu_count())}
+            out['parity_checked_images'] = ncpu
+            out['parity_ok'] = bool(ok)
+    for e in engs:
+        e.close()
+    return out
 
 
 if __name__ == '__main__':

@@ -223,6 +223,18 @@ class Context:
         cw = (C.c_int32 * n)(*[c[1] for c in crops])
         self.check(self.L.pd_upsample_avg(self._h, n, hp, pp, hs, ws, ch, cw, H, W, B, MEM_HOST))
 
+    def upsample_avg_device(self, heat_ptrs, paf_ptrs, sizes, crops, H, W, B):
+        """The same for device-resident network outputs: addresses of the (B, hs, ws, 19) and
+        (B, hs, ws, 38) float32 arrays of every scale, ``sizes[m] = (hs, ws)``."""
+        n = len(heat_ptrs)
+        hp = (C.c_void_p * n)(*heat_ptrs)
+        pp = (C.c_void_p * n)(*paf_ptrs)
+        hs = (C.c_int32 * n)(*[s[0] for s in sizes])
+        ws = (C.c_int32 * n)(*[s[1] for s in sizes])
+        ch = (C.c_int32 * n)(*[c[0] for c in crops])
+        cw = (C.c_int32 * n)(*[c[1] for c in crops])
+        self.check(self.L.pd_upsample_avg(self._h, n, hp, pp, hs, ws, ch, cw, H, W, B, MEM_DEVICE))
+
     def read_fullres(self, B, H, W, want_heat=True, want_paf=True):
         heat = np.empty((B, H, W, 19), np.float64) if want_heat else None
         paf = np.empty((B, H, W, 38), np.float64) if want_paf else None

@@ -164,7 +164,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
     stop_worker(ctx);
     (void)hipSetDevice(ctx->cfg.device_id);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    void* ptrs[] = {ctx->stage_heat, ctx->stage_paf, ctx->full_heat, ctx->full_paf, ctx->tmp_up, ctx->tmp_in,
+    void* ptrs[] = {ctx->stage_heat, ctx->stage_paf, ctx->full_heat, ctx->full_paf, ctx->tmp_in,
                     ctx->tmp_smooth, ctx->tmp_smooth2, ctx->raw, ctx->zero_block, ctx->pk_y,
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
@@ -360,15 +360,8 @@ extern "C" int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* he
     if (n_scales > PD_MAX_SCALES) PD_FAIL(ctx, PD_E_INVALID, "pd_upsample_avg: at most %d scales", PD_MAX_SCALES);
     rc = ensure_full(ctx, B, H, W, true, true);
     if (rc != PD_OK) return rc;
-    // the x8 maps of all scales of one family (19 or 38 channels) are alive together, so
-    // that the average is formed in one pass that writes every output once
-    size_t n_lo_all = 0, n_up_all = 0;
-    for (int m = 0; m < n_scales; ++m) {
-        n_lo_all += (size_t)B * hs[m] * ws[m];
-        n_up_all += (size_t)B * 64 * hs[m] * ws[m];
-    }
-    rc = ensure(ctx, (void**)&ctx->tmp_up, &ctx->tmp_up_cap, n_up_all * PD_CH_PAF * sizeof(float));
-    if (rc != PD_OK) return rc;
+    size_t n_lo_all = 0;
+    for (int m = 0; m < n_scales; ++m) n_lo_all += (size_t)B * hs[m] * ws[m];
     for (int which = 0; which < 2; ++which) {
         const int C = which == 0 ? PD_CH_HEAT : PD_CH_PAF;
         const float* const* given = which == 0 ? heat : paf;
@@ -389,7 +382,7 @@ extern "C" int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* he
         } else {
             for (int m = 0; m < n_scales; ++m) srcs[m] = given[m];
         }
-        rc = pd_launch_upsample_avg(ctx, n_scales, srcs, C, B, hs, ws, crop_h, crop_w, ctx->tmp_up, dst, H, W);
+        rc = pd_launch_upsample_avg(ctx, n_scales, srcs, C, B, hs, ws, crop_h, crop_w, dst, H, W);
         if (rc != PD_OK) return rc;
     }
     ctx->src_kind = PD_SRC_FULLRES;

@@ -149,8 +149,6 @@ struct pd_ctx {
     double* full_paf;   // (B, 38, H, W)
     size_t full_heat_cap, full_paf_cap;
     int have_full_heat, have_full_paf;
-    float* tmp_up;  // x8 maps of one scale, planar float32
-    size_t tmp_up_cap;
     void* tmp_in;  // staging for host-resident full-resolution input
     size_t tmp_in_cap;
     double* tmp_smooth;  // (B, 18, H, W) scratch of the simple path / debug hook
@@ -329,7 +327,6 @@ int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W);
 void pd_host_cubic_table(int src_len, int dst_len, double scale, int32_t* ofs, float* coef);
 void pd_up8_fill(Up8* u);
 int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
-                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, float* up, double* dst,
-                           int H, int W);
+                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W);
 MapSource pd_heat_source(const pd_ctx* ctx);
 MapSource pd_paf_source(const pd_ctx* ctx);

@@ -10,6 +10,7 @@
 // separately rounded multiply and add; equal source and destination size = copy.
 #include <math.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -124,115 +125,35 @@ __global__ void k_planar_to_hwc(const double* __restrict__ src, int C, int H, in
     dst[(size_t)b * n + i] = src[((size_t)b * C + ch) * (size_t)H * W + px];
 }
 
-// ---- x8 upsample, eight output rows per thread ------------------------------------------
-// Output rows 8j-4 .. 8j+3 draw on the same four source rows (j-2 .. j+1, clamped) and
-// differ only in the phase of their weights, so a thread forms the four horizontal sums of
-// its column once and combines them eight times.  Per output: the horizontal 4-tap sum of each source row, then the vertical 4-tap sum,
-// float32, multiplies and adds rounded separately.
-__global__ void __launch_bounds__(256)
-k_resize_up8(const float* __restrict__ src, int C, int hs, int ws, Up8 up, float* __restrict__ dst) {
-    __shared__ float4 s_up[8];
-    if (threadIdx.x < 8) s_up[threadIdx.x] = make_float4(up.c[threadIdx.x][0], up.c[threadIdx.x][1], up.c[threadIdx.x][2], up.c[threadIdx.x][3]);
-    __syncthreads();
-    const int Hd = 8 * hs, Wd = 8 * ws;
-    const int X = blockIdx.x * 256 + threadIdx.x;
-    if (X >= Wd) return;
-    const int j = blockIdx.y;                 // 0 .. hs
-    const int ch = blockIdx.z % C, b = blockIdx.z / C;
-    const int x0 = pd_up8_ofs(X);
-    const float4 ac = s_up[pd_up8_phase(X)];
-    const int xi0 = pd_clampi(x0, 0, ws - 1) * C, xi1 = pd_clampi(x0 + 1, 0, ws - 1) * C,
-              xi2 = pd_clampi(x0 + 2, 0, ws - 1) * C, xi3 = pd_clampi(x0 + 3, 0, ws - 1) * C;
-    const float* img = src + (size_t)b * hs * ws * C + ch;
-    float hsum[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float* row = img + (size_t)pd_clampi(j - 2 + k, 0, hs - 1) * ws * C;
-        hsum[k] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
-    }
-    float* out = dst + ((size_t)b * C + ch) * (size_t)Hd * Wd + X;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int d = 8 * j - 4 + p;
-        if (d >= 0 && d < Hd)
-            out[(size_t)d * Wd] = ((hsum[0] * up.c[p][0] + hsum[1] * up.c[p][1]) + hsum[2] * up.c[p][2]) + hsum[3] * up.c[p][3];
-    }
-}
-
-// ---- second resize of every scale + average, one pass -------------------------------------
+// ---- x8 upsample + second resize of every scale + average, one pass ----------------------
 // out = ((0 + v_0 / n) + v_1 / n) + ..  with v_m the crop of scale m's x8 map resized to
-// (H, W) (predict.py:64-65, 71-72): float32 division, float64 accumulation in scale order.
+// (H, W) (predict.py:63-65, 71-72): float32 division, float64 accumulation in scale order.
+// The x8 maps are never written to memory: a workgroup owns a 32 x 8 output tile of four
+// channels and, per scale, builds the part of the x8 map its taps fall in (the "patch") in
+// LDS straight from the network output, in the reference's order of operations --
+//   A  horizontal 4-tap sums of the source rows the patch draws on        (cv2.resize x8, row pass)
+//   B  vertical 4-tap sums of those: the patch of the x8 map               (cv2.resize x8, column pass)
+//   C  per output pixel: 4 horizontal sums over the patch, then the vertical sum   (second resize)
+// every sum ((s0*c0 + s1*c1) + s2*c2) + s3*c3 in float32 with separately rounded products.
 struct ScaleSrc {
-    const float* up;   // planar (B, C, Hs, Ws) float32
-    int Hs, Ws, crop_h, crop_w, identity;
-    CubicTable ty, tx;
+    const float* lo;   // (B, hs, ws, C) float32 network output of this scale
+    int hs, ws, crop_h, crop_w, identity;
+    CubicTable ty, tx; // second resize: crop -> (H, W)
 };
 struct AvgArgs {
     ScaleSrc s[PD_MAX_SCALES];
     int n_scales, C, H, W;
     float n_div, n_rcp;   // number of scales; its reciprocal when that is exact (a power of two)
+    Up8 up8;
     double* dst;          // planar (B, C, H, W)
 };
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
-#ifndef AVG_TW
-#define AVG_TW 32       // output tile of a workgroup: AVG_TW x AVG_TH = 256 pixels
-#endif
-#define AVG_TH (256 / AVG_TW)
-#ifndef AVG_CH
-#define AVG_CH 4        // channels per workgroup: taps and weights of a pixel are set up once per scale for all of
-#endif                  // them; with 8 the kernel needs 182 registers and two workgroups per CU cannot hide its loads
-#ifndef AVG_SLOTS
-#define AVG_SLOTS 6     // patch elements per thread and channel
-#endif
-#define AVG_PATCH (AVG_SLOTS * 256)
-
-// What a scale contributes to the workgroup's 32 x 8 output tile, fetched ahead of its use.
-// Patch form: the part of the x8 map the tile's taps fall in, rows r_lo .. r_lo+ph-1 and
-// columns c_lo .. c_lo+pw-1, read with coalesced loads (element e = row * pw + col, thread
-// tid takes e = tid + 256 s) and handed to the other threads through LDS.  An identity
-// scale is the thread's own pixel; a patch beyond AVG_PATCH elements (a downscale by more
-// than 2.1) is not staged: its taps are gathered from memory.
-struct AvgFetch {
-    int kind;  // 0 identity, 1 patch, 2 gather
-    int r_lo, c_lo, ph, pw;
-    float v[AVG_SLOTS][AVG_CH];
-};
-
-__device__ __forceinline__ void avg_fetch(const AvgArgs& a, int m, int b, int ch0, int nch, int X0, int Y0, int X, int Y,
-                                          bool inside, int tid, AvgFetch& f) {
-    const ScaleSrc& sc = a.s[m];
-    const size_t plane = (size_t)sc.Hs * sc.Ws;
-    const float* p = sc.up + ((size_t)b * a.C + ch0) * plane;
-    if (sc.identity) {
-        f.kind = 0;
-        const size_t o = (size_t)Y * sc.Ws + X;
-#pragma unroll
-        for (int c = 0; c < AVG_CH; ++c) f.v[0][c] = (inside && c < nch) ? p[c * plane + o] : 0.f;
-        return;
-    }
-    // the offsets grow with the output coordinate: the tile's first and last give the range
-    const int y_first = sc.ty.ofs[Y0], y_last = sc.ty.ofs[min(Y0 + AVG_TH - 1, a.H - 1)];
-    const int x_first = sc.tx.ofs[X0], x_last = sc.tx.ofs[min(X0 + AVG_TW - 1, a.W - 1)];
-    f.r_lo = pd_clampi(y_first, 0, sc.crop_h - 1);
-    f.c_lo = pd_clampi(x_first, 0, sc.crop_w - 1);
-    f.ph = pd_clampi(y_last + 3, 0, sc.crop_h - 1) - f.r_lo + 1;
-    f.pw = pd_clampi(x_last + 3, 0, sc.crop_w - 1) - f.c_lo + 1;
-    if (f.ph * f.pw > AVG_PATCH) {
-        f.kind = 2;
-        return;
-    }
-    f.kind = 1;
-    const int pe = f.ph * f.pw;
-#pragma unroll
-    for (int s = 0; s < AVG_SLOTS; ++s) {
-        const int e = tid + 256 * s;
-        const int row = e / f.pw, col = e - row * f.pw;
-        const float* g = p + (size_t)(f.r_lo + row) * sc.Ws + f.c_lo + col;
-#pragma unroll
-        for (int c = 0; c < AVG_CH; ++c) f.v[s][c] = (e < pe && c < nch) ? g[c * plane] : 0.f;
-    }
-}
+#define FT_TW 32        // output tile of a workgroup: FT_TW x FT_TH = 256 pixels
+#define FT_TH 8
+#define FT_CH 4         // channels per workgroup: they are adjacent in the (h, w, C) source, one 16-byte load
+#define FT_PATCH 1536   // x8-map values per channel staged in LDS (a downscale up to about 2.1)
+#define FT_HSUM 768     // horizontal sums per channel staged in LDS
 
 // v / n as the reference's float32 division rounds it; for a power of two the product with
 // the reciprocal is the same number.
@@ -241,135 +162,254 @@ __device__ __forceinline__ float avg_share(float v, const AvgArgs& a) {
     return POW2 ? v * a.n_rcp : v / a.n_div;
 }
 
-template <bool POW2>
-__global__ void __launch_bounds__(256)
-k_resize_avg(AvgArgs a) {
-    __shared__ __align__(16) float patch[AVG_CH][AVG_PATCH];
+// nch adjacent channels of one source pixel (the others zero).
+__device__ __forceinline__ float4 load_channels(const float* p, int nch) {
+    if (nch == FT_CH) {
+        const float4u t = *(const float4u*)p;
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    float4 r = make_float4(p[0], 0.f, 0.f, 0.f);
+    if (nch > 1) r.y = p[1];
+    if (nch > 2) r.z = p[2];
+    return r;
+}
+
+__device__ __forceinline__ float tap4(float s0, float s1, float s2, float s3, const float4& c) {
+    return ((s0 * c.x + s1 * c.y) + s2 * c.z) + s3 * c.w;
+}
+
+// Horizontal sums of source row srow at x8-map column col, FT_CH channels.
+__device__ __forceinline__ float4 hsum_at(const float* img, int ws, int C, int srow, int col, int nch, const float4* s_up) {
+    const int x0 = pd_up8_ofs(col);
+    const float4 w = s_up[pd_up8_phase(col)];
+    const float* row = img + (size_t)srow * ws * C;
+    const float4 v0 = load_channels(row + (size_t)pd_clampi(x0, 0, ws - 1) * C, nch);
+    const float4 v1 = load_channels(row + (size_t)pd_clampi(x0 + 1, 0, ws - 1) * C, nch);
+    const float4 v2 = load_channels(row + (size_t)pd_clampi(x0 + 2, 0, ws - 1) * C, nch);
+    const float4 v3 = load_channels(row + (size_t)pd_clampi(x0 + 3, 0, ws - 1) * C, nch);
+    return make_float4(tap4(v0.x, v1.x, v2.x, v3.x, w), tap4(v0.y, v1.y, v2.y, v3.y, w),
+                       tap4(v0.z, v1.z, v2.z, v3.z, w), tap4(v0.w, v1.w, v2.w, v3.w, w));
+}
+
+// One value of the x8 map at (row, col), straight from the source (patches too large to stage).
+__device__ __forceinline__ float4 up8_at(const float* img, int hs, int ws, int C, int row, int col, int nch, const float4* s_up) {
+    const int y0 = pd_up8_ofs(row);
+    const float4 w = s_up[pd_up8_phase(row)];
+    const float4 h0 = hsum_at(img, ws, C, pd_clampi(y0, 0, hs - 1), col, nch, s_up);
+    const float4 h1 = hsum_at(img, ws, C, pd_clampi(y0 + 1, 0, hs - 1), col, nch, s_up);
+    const float4 h2 = hsum_at(img, ws, C, pd_clampi(y0 + 2, 0, hs - 1), col, nch, s_up);
+    const float4 h3 = hsum_at(img, ws, C, pd_clampi(y0 + 3, 0, hs - 1), col, nch, s_up);
+    return make_float4(tap4(h0.x, h1.x, h2.x, h3.x, w), tap4(h0.y, h1.y, h2.y, h3.y, w),
+                       tap4(h0.z, h1.z, h2.z, h3.z, w), tap4(h0.w, h1.w, h2.w, h3.w, w));
+}
+
+// DIRECT: some scale's patches do not fit the staging area (decided on the host from the tap
+// tables); the common kernel carries no code for that case, so that it stays within the
+// registers of four workgroups per CU.
+template <bool POW2, bool DIRECT>
+__global__ void __launch_bounds__(256, DIRECT ? 1 : 4)
+k_resize_fused(AvgArgs a) {
+    __shared__ __align__(16) float patch[FT_CH][FT_PATCH];
+    __shared__ __align__(16) float hsum[FT_CH][FT_HSUM];
+    __shared__ float4 s_up[8];
+    const int tid = threadIdx.x;
+    if (tid < 8) s_up[tid] = make_float4(a.up8.c[tid][0], a.up8.c[tid][1], a.up8.c[tid][2], a.up8.c[tid][3]);
     const size_t n = (size_t)a.H * a.W;
     // Workgroup i runs on XCD i % 8, each with an L2 of its own: XCD x takes the x-th eighth
-    // of the tiles in row-major order, so that tiles sharing rows and lines share an L2.
-    const int tiles_x = (a.W + AVG_TW - 1) / AVG_TW, tiles = tiles_x * ((a.H + AVG_TH - 1) / AVG_TH);
+    // of the tiles in row-major order, so that tiles sharing source rows share an L2.
+    const int tiles_x = (a.W + FT_TW - 1) / FT_TW, tiles = tiles_x * ((a.H + FT_TH - 1) / FT_TH);
     const int per_xcd = (tiles + 7) / 8;
     const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile >= tiles) return;
-    const int tid = threadIdx.x;
-    const int X0 = (tile % tiles_x) * AVG_TW, Y0 = (tile / tiles_x) * AVG_TH;
-    const bool inside = X0 + (tid % AVG_TW) < a.W && Y0 + (tid / AVG_TW) < a.H;
-    // threads beyond the map keep step with the others (they load and stage, and store nothing)
-    const int X = min(X0 + (tid % AVG_TW), a.W - 1), Y = min(Y0 + (tid / AVG_TW), a.H - 1);
-    const size_t i = (size_t)Y * a.W + X;
-    const int ch0 = blockIdx.y * AVG_CH, b = blockIdx.z;
-    const int nch = min(AVG_CH, a.C - ch0);
-    double acc[AVG_CH];
+    const int X0 = (tile % tiles_x) * FT_TW, Y0 = (tile / tiles_x) * FT_TH;
+    const bool inside = X0 + (tid % FT_TW) < a.W && Y0 + (tid / FT_TW) < a.H;
+    // threads beyond the map keep step with the others (they help build the patch and store nothing)
+    const int X = min(X0 + (tid % FT_TW), a.W - 1), Y = min(Y0 + (tid / FT_TW), a.H - 1);
+    const int Ylast = min(Y0 + FT_TH - 1, a.H - 1), Xlast = min(X0 + FT_TW - 1, a.W - 1);
+    const int ch0 = blockIdx.y * FT_CH, b = blockIdx.z;
+    const int nch = min(FT_CH, a.C - ch0);
+    double acc[FT_CH];
 #pragma unroll
-    for (int c = 0; c < AVG_CH; ++c) acc[c] = 0.0;
-    AvgFetch f;
-    avg_fetch(a, 0, b, ch0, nch, X0, Y0, X, Y, inside, tid, f);
+    for (int c = 0; c < FT_CH; ++c) acc[c] = 0.0;
+    __syncthreads();
     for (int m = 0; m < a.n_scales; ++m) {
         const ScaleSrc& sc = a.s[m];
-        const int kind = f.kind, r_lo = f.r_lo, c_lo = f.c_lo, pw = f.pw;
-        if (kind == 0) {
-#pragma unroll
-            for (int c = 0; c < AVG_CH; ++c)
-                if (c < nch) acc[c] = acc[c] + (double)avg_share<POW2>(f.v[0][c], a);
-            if (m + 1 < a.n_scales) avg_fetch(a, m + 1, b, ch0, nch, X0, Y0, X, Y, inside, tid, f);
-            continue;
-        }
-        if (kind == 1) {
-            const int pe = f.ph * f.pw;
-#pragma unroll
-            for (int s = 0; s < AVG_SLOTS; ++s) {
-                const int e = tid + 256 * s;
-                if (e < pe) {
-#pragma unroll
-                    for (int c = 0; c < AVG_CH; ++c) patch[c][e] = f.v[s][c];
-                }
-            }
-        }
-        __syncthreads();
-        // the next scale's loads are in flight while this one is evaluated
-        if (m + 1 < a.n_scales) avg_fetch(a, m + 1, b, ch0, nch, X0, Y0, X, Y, inside, tid, f);
-        const int x0 = sc.tx.ofs[X], y0 = sc.ty.ofs[Y];
-        const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)X);
-        const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Y);
-        const int xi0 = pd_clampi(x0, 0, sc.crop_w - 1), xi1 = pd_clampi(x0 + 1, 0, sc.crop_w - 1),
-                  xi2 = pd_clampi(x0 + 2, 0, sc.crop_w - 1), xi3 = pd_clampi(x0 + 3, 0, sc.crop_w - 1);
-        // away from the left and right border the four taps are adjacent
-        const bool adjacent = x0 >= 0 && x0 + 3 <= sc.crop_w - 1;
-        if (kind == 1) {
-            int ro[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ro[k] = (pd_clampi(y0 + k, 0, sc.crop_h - 1) - r_lo) * pw - c_lo;
-#pragma unroll
-            for (int c = 0; c < AVG_CH; ++c) {
-                if (c < nch) {
-                    const float* q = patch[c];
-                    float hv[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float* row = q + ro[k];
-                        if (adjacent) {
-                            const float4u t = *(const float4u*)(row + x0);
-                            hv[k] = ((t.x * ac.x + t.y * ac.y) + t.z * ac.z) + t.w * ac.w;
-                        } else {
-                            hv[k] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
-                        }
-                    }
-                    const float v = ((hv[0] * bc.x + hv[1] * bc.y) + hv[2] * bc.z) + hv[3] * bc.w;
-                    acc[c] = acc[c] + (double)avg_share<POW2>(v, a);
-                }
-            }
+        const float* img = sc.lo + (size_t)b * sc.hs * sc.ws * a.C + ch0;
+        // the part of the x8 map this tile's taps fall in: rows r_lo .. r_lo+ph-1, columns
+        // c_lo .. c_lo+pw-1 (tap offsets grow with the output coordinate)
+        int r_lo, c_lo, ph, pw;
+        if (sc.identity) {
+            r_lo = Y0;
+            c_lo = X0;
+            ph = Ylast - Y0 + 1;
+            pw = Xlast - X0 + 1;
         } else {
-            const size_t plane = (size_t)sc.Hs * sc.Ws;
-            const float* p = sc.up + ((size_t)b * a.C + ch0) * plane;
-            int ro[4];
+            r_lo = pd_clampi(sc.ty.ofs[Y0], 0, sc.crop_h - 1);
+            c_lo = pd_clampi(sc.tx.ofs[X0], 0, sc.crop_w - 1);
+            ph = pd_clampi(sc.ty.ofs[Ylast] + 3, 0, sc.crop_h - 1) - r_lo + 1;
+            pw = pd_clampi(sc.tx.ofs[Xlast] + 3, 0, sc.crop_w - 1) - c_lo + 1;
+        }
+        const int j_lo = pd_up8_ofs(r_lo);                         // first source row (unclamped)
+        const int nj = pd_up8_ofs(r_lo + ph - 1) + 3 - j_lo + 1;   // source rows the patch draws on
+        const bool staged = !DIRECT || (ph * pw <= FT_PATCH && nj * pw <= FT_HSUM);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (staged) {
+            // A: horizontal sums, element e = source row jj, patch column c
+            for (int e = tid; e < nj * pw; e += 256) {
+                const int jj = e / pw, c = e - jj * pw;
+                const float4 hsv = hsum_at(img, sc.ws, a.C, pd_clampi(j_lo + jj, 0, sc.hs - 1), c_lo + c, nch, s_up);
+                hsum[0][e] = hsv.x;
+                hsum[1][e] = hsv.y;
+                hsum[2][e] = hsv.z;
+                hsum[3][e] = hsv.w;
+            }
+            __syncthreads();
+            // B: the patch.  A thread walks down a run of rows of one column and keeps the four
+            // horizontal sums in use in registers (the first tap row advances every eighth row).
+            const int G = max(1, 256 / pw), rpg = (ph + G - 1) / G;
+            for (int it = tid; it < G * pw; it += 256) {
+                const int g = it / pw, c = it - g * pw;
+                const int r1 = min(ph, (g + 1) * rpg);
+                int cur = -0x40000000;
+                float hv[4][FT_CH];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ro[k] = pd_clampi(y0 + k, 0, sc.crop_h - 1) * sc.Ws;
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int c = 0; c < AVG_CH; ++c) {
-                if (c < nch) {
-                    const float* q = p + c * plane;
-                    float hv[4];
+                    for (int q = 0; q < FT_CH; ++q) hv[k][q] = 0.f;
+                for (int r = g * rpg; r < r1; ++r) {
+                    const int rabs = r_lo + r;
+                    const int y0 = pd_up8_ofs(rabs) - j_lo;
+                    if (y0 == cur + 1) {
+#pragma unroll
+                        for (int q = 0; q < FT_CH; ++q) {
+                            hv[0][q] = hv[1][q];
+                            hv[1][q] = hv[2][q];
+                            hv[2][q] = hv[3][q];
+                            hv[3][q] = hsum[q][(y0 + 3) * pw + c];
+                        }
+                    } else if (y0 != cur) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int q = 0; q < FT_CH; ++q) hv[k][q] = hsum[q][(y0 + k) * pw + c];
+                    }
+                    cur = y0;
+                    const float4 w = s_up[pd_up8_phase(rabs)];
+#pragma unroll
+                    for (int q = 0; q < FT_CH; ++q) patch[q][r * pw + c] = tap4(hv[0][q], hv[1][q], hv[2][q], hv[3][q], w);
+                }
+            }
+            __syncthreads();
+            // C: the second resize from the patch
+            if (sc.identity) {
+                const int o = (Y - r_lo) * pw + (X - c_lo);
+                v = make_float4(patch[0][o], patch[1][o], patch[2][o], patch[3][o]);
+            } else {
+                const int x0 = sc.tx.ofs[X], y0 = sc.ty.ofs[Y];
+                const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)X);
+                const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Y);
+                const int xi0 = pd_clampi(x0, 0, sc.crop_w - 1) - c_lo, xi1 = pd_clampi(x0 + 1, 0, sc.crop_w - 1) - c_lo,
+                          xi2 = pd_clampi(x0 + 2, 0, sc.crop_w - 1) - c_lo, xi3 = pd_clampi(x0 + 3, 0, sc.crop_w - 1) - c_lo;
+                int ro[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ro[k] = (pd_clampi(y0 + k, 0, sc.crop_h - 1) - r_lo) * pw;
+                float o4[FT_CH];
+#pragma unroll
+                for (int q = 0; q < FT_CH; ++q) {
+                    const float* p = patch[q];
+                    float hvv[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float* row = q + ro[k];
-                        if (adjacent) {
-                            const float4u t = *(const float4u*)(row + x0);
-                            hv[k] = ((t.x * ac.x + t.y * ac.y) + t.z * ac.z) + t.w * ac.w;
-                        } else {
-                            hv[k] = ((row[xi0] * ac.x + row[xi1] * ac.y) + row[xi2] * ac.z) + row[xi3] * ac.w;
-                        }
+                        const float* row = p + ro[k];
+                        hvv[k] = tap4(row[xi0], row[xi1], row[xi2], row[xi3], ac);
                     }
-                    const float v = ((hv[0] * bc.x + hv[1] * bc.y) + hv[2] * bc.z) + hv[3] * bc.w;
-                    acc[c] = acc[c] + (double)avg_share<POW2>(v, a);
+                    o4[q] = tap4(hvv[0], hvv[1], hvv[2], hvv[3], bc);
+                }
+                v = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
+        } else if (DIRECT) {
+            // a patch too large to stage (a strong downscale): every tap of the second resize is
+            // formed from the source on the spot
+            const int x0 = sc.tx.ofs[X], y0 = sc.ty.ofs[Y];
+            const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)X);
+            const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Y);
+            if (sc.identity) {
+                v = up8_at(img, sc.hs, sc.ws, a.C, Y, X, nch, s_up);
+            } else {
+                // sums built up left to right, one tap at a time (loops kept rolled: this path is rare
+                // and must not cost the kernel its registers)
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {
+                    const int r = pd_clampi(y0 + k, 0, sc.crop_h - 1);
+                    float4 hs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 u = up8_at(img, sc.hs, sc.ws, a.C, r, pd_clampi(x0 + t, 0, sc.crop_w - 1), nch, s_up);
+                        const float cw = t == 0 ? ac.x : (t == 1 ? ac.y : (t == 2 ? ac.z : ac.w));
+                        if (t == 0)
+                            hs4 = make_float4(u.x * cw, u.y * cw, u.z * cw, u.w * cw);
+                        else
+                            hs4 = make_float4(hs4.x + u.x * cw, hs4.y + u.y * cw, hs4.z + u.z * cw, hs4.w + u.w * cw);
+                    }
+                    const float rw = k == 0 ? bc.x : (k == 1 ? bc.y : (k == 2 ? bc.z : bc.w));
+                    if (k == 0)
+                        v = make_float4(hs4.x * rw, hs4.y * rw, hs4.z * rw, hs4.w * rw);
+                    else
+                        v = make_float4(v.x + hs4.x * rw, v.y + hs4.y * rw, v.z + hs4.z * rw, v.w + hs4.w * rw);
                 }
             }
         }
-        __syncthreads();  // the patch is free for the next scale
+        acc[0] = acc[0] + (double)avg_share<POW2>(v.x, a);
+        acc[1] = acc[1] + (double)avg_share<POW2>(v.y, a);
+        acc[2] = acc[2] + (double)avg_share<POW2>(v.z, a);
+        acc[3] = acc[3] + (double)avg_share<POW2>(v.w, a);
+        // no barrier here: the next scale's pass A writes hsum only (every thread is past
+        // this scale's pass B), and its pass B writes the patch behind a barrier of its own
     }
     if (!inside) return;
-    double* out = a.dst + ((size_t)b * a.C + ch0) * n + i;
+    double* out = a.dst + ((size_t)b * a.C + ch0) * n + (size_t)Y * a.W + X;
 #pragma unroll
-    for (int c = 0; c < AVG_CH; ++c)
+    for (int c = 0; c < FT_CH; ++c)
         if (c < nch) out[c * n] = acc[c];
 }
 
-// All scales of one map family (C = 19 or 38): srcs[m] is (B, hs[m], ws[m], C) on the
-// device; up holds the x8 maps of all scales one after the other.
+// Whether every tile's patch of the second resize (crop -> H x W) fits the staging areas of
+// k_resize_fused; the same extents the kernel derives from the device tables.
+static bool patches_fit(int crop_h, int crop_w, int H, int W) {
+    std::vector<int32_t> oy(H), ox(W);
+    std::vector<float> cy(4 * (size_t)H), cx(4 * (size_t)W);
+    pd_host_cubic_table(crop_h, H, -1.0, oy.data(), cy.data());
+    pd_host_cubic_table(crop_w, W, -1.0, ox.data(), cx.data());
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    int max_ph = 0, max_pw = 0, max_nj = 0;
+    for (int Y0 = 0; Y0 < H; Y0 += FT_TH) {
+        const int Yl = std::min(Y0 + FT_TH - 1, H - 1);
+        const int r_lo = clampi(oy[Y0], 0, crop_h - 1);
+        const int ph = clampi(oy[Yl] + 3, 0, crop_h - 1) - r_lo + 1;
+        const int nj = pd_up8_ofs(r_lo + ph - 1) + 3 - pd_up8_ofs(r_lo) + 1;
+        max_ph = std::max(max_ph, ph);
+        max_nj = std::max(max_nj, nj);
+    }
+    for (int X0 = 0; X0 < W; X0 += FT_TW) {
+        const int Xl = std::min(X0 + FT_TW - 1, W - 1);
+        const int c_lo = clampi(ox[X0], 0, crop_w - 1);
+        max_pw = std::max(max_pw, clampi(ox[Xl] + 3, 0, crop_w - 1) - c_lo + 1);
+    }
+    return max_ph * max_pw <= FT_PATCH && max_nj * max_pw <= FT_HSUM;
+}
+
+// All scales of one map family (C = 19 or 38): srcs[m] is (B, hs[m], ws[m], C) on the device.
 int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
-                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, float* up, double* dst,
-                           int H, int W) {
+                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W) {
     AvgArgs a;
     memset(&a, 0, sizeof(a));
-    Up8 u8;
-    pd_up8_fill(&u8);
-    size_t off = 0;
+    pd_up8_fill(&a.up8);
+    bool direct = false;
     for (int m = 0; m < n_scales; ++m) {
-        const int Hs = 8 * hs[m], Ws = 8 * ws[m];
         ScaleSrc& sc = a.s[m];
-        sc.up = up + off;
-        sc.Hs = Hs;
-        sc.Ws = Ws;
+        sc.lo = srcs[m];
+        sc.hs = hs[m];
+        sc.ws = ws[m];
         sc.crop_h = crop_h[m];
         sc.crop_w = crop_w[m];
         sc.identity = crop_h[m] == H && crop_w[m] == W;
@@ -378,12 +418,8 @@ int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, 
             if (rc != PD_OK) return rc;
             sc.ty = ctx->tabs[2 + m].ty;
             sc.tx = ctx->tabs[2 + m].tx;
+            if (!patches_fit(crop_h[m], crop_w[m], H, W)) direct = true;
         }
-        pd_prof_begin(ctx, PD_STAGE_RESIZE);
-        hipLaunchKernelGGL(k_resize_up8, dim3((Ws + 255) / 256, hs[m] + 1, C * B), dim3(256), 0, ctx->stream, srcs[m], C,
-                           hs[m], ws[m], u8, up + off);
-        pd_prof_end(ctx);
-        off += (size_t)B * C * Hs * Ws;
     }
     a.n_scales = n_scales;
     a.C = C;
@@ -391,15 +427,19 @@ int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, 
     a.W = W;
     a.n_div = (float)n_scales;
     a.dst = dst;
-    const unsigned tiles = (unsigned)(((W + AVG_TW - 1) / AVG_TW) * ((H + AVG_TH - 1) / AVG_TH));
+    const unsigned tiles = (unsigned)(((W + FT_TW - 1) / FT_TW) * ((H + FT_TH - 1) / FT_TH));
     pd_prof_begin(ctx, PD_STAGE_RESIZE);
-    const dim3 grid((tiles + 7) / 8 * 8, (C + AVG_CH - 1) / AVG_CH, B);
-    if ((n_scales & (n_scales - 1)) == 0) {
-        a.n_rcp = 1.0f / (float)n_scales;
-        hipLaunchKernelGGL(k_resize_avg<true>, grid, dim3(256), 0, ctx->stream, a);
-    } else {
-        hipLaunchKernelGGL(k_resize_avg<false>, grid, dim3(256), 0, ctx->stream, a);
-    }
+    const dim3 grid((tiles + 7) / 8 * 8, (C + FT_CH - 1) / FT_CH, B);
+    const bool pow2 = (n_scales & (n_scales - 1)) == 0;
+    if (pow2) a.n_rcp = 1.0f / (float)n_scales;
+    if (pow2 && !direct)
+        hipLaunchKernelGGL((k_resize_fused<true, false>), grid, dim3(256), 0, ctx->stream, a);
+    else if (pow2)
+        hipLaunchKernelGGL((k_resize_fused<true, true>), grid, dim3(256), 0, ctx->stream, a);
+    else if (!direct)
+        hipLaunchKernelGGL((k_resize_fused<false, false>), grid, dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_resize_fused<false, true>), grid, dim3(256), 0, ctx->stream, a);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;

@@ -126,3 +126,125 @@ def test_four_scales_at_368():
         np.testing.assert_array_equal(res.candidate(b), cand)
         gio.assert_persons_equal(res.subset(b), subset, RTOL)
     eng.close()
+
+
+def test_config4_batch_128_four_scales():
+    """BASELINE config 4 at its size on one GPU: 128 images x scales (0.5, 1, 1.5, 2) at 368^2
+    through predict.py:49-72 (x8 bicubic, resize, average) and the decode.  A sample of images
+    against the oracle's upsample_average + decode, size-independent properties on all 128."""
+    from poseestimation_amd import synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    B, H, W = 128, 368, 368
+    scales = [0.5, 1.0, 1.5, 2.0]
+    heats, pafs = [], []
+    for s in scales:
+        outs = [synth.scene(H, W, 1 + b % 8, 4000 + b, paf_order='xy', scale=s) for b in range(B)]
+        heats.append(np.stack([o[0] for o in outs]))
+        pafs.append(np.stack([o[1] for o in outs]))
+    assert [h.shape[1] for h in heats] == [23, 46, 69, 92]
+    pads = [(0, 0)] * 4
+    eng = DecodeEngine(B, H, W, mode='D', max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000)
+    res = eng.decode_multiscale(heats, pafs, pads, (H, W))
+    again = eng.decode_multiscale(heats, pafs, pads, (H, W))
+    for key in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
+        assert np.array_equal(res.packed[key], again.packed[key]), key       # deterministic
+    for b in (0, 77, 127):
+        want_h, want_p = ref.upsample_average([h[b] for h in heats], [p[b] for p in pafs], pads, (H, W))
+        cand, peaks, subset = ref.decode(want_h, want_p, 0.1, 0.05, 'D')
+        gio.assert_peaks_equal(res.all_peaks(b), peaks, exact_score=True)
+        np.testing.assert_array_equal(res.candidate(b), cand)
+        conns, special = ref.get_connections(peaks, want_p, 0.05, 'D')
+        g_conns, g_special = res.connections(b)
+        assert g_special == special
+        gio.assert_conns_equal(g_conns, conns, RTOL)
+        gio.assert_persons_equal(res.subset(b), subset, RTOL)
+    n_persons = 0
+    for b in range(B):
+        peaks = res.all_peaks(b)
+        conns, special = res.connections(b)
+        subset = res.subset(b)
+        n_persons += len(subset)
+        gio.assert_persons_equal(subset, ref.multi_person_parse(peaks, conns, special, 'D'), RTOL)
+        flat = [t for pl in peaks for t in pl]
+        assert [t[3] for t in flat] == list(range(len(flat)))
+        for pl in peaks:
+            keys = [int(t[1]) * W + int(t[0]) for t in pl]
+            assert keys == sorted(keys) and len(set(keys)) == len(keys)
+        for k, c in enumerate(conns):
+            if k in special:
+                continue
+            assert np.all(np.diff(c[:, 2]) <= 0)
+            assert len(set(c[:, 0])) == len(c) and len(set(c[:, 1])) == len(c)
+    assert n_persons >= B        # 1..8 people per image
+    # an image decodes the same alone as inside the batch
+    solo = DecodeEngine(1, H, W, mode='D')
+    for b in (5, 100):
+        one = solo.decode_multiscale([h[b:b + 1] for h in heats], [p[b:b + 1] for p in pafs], pads, (H, W))
+        np.testing.assert_array_equal(one.subset(0), res.subset(b))
+        assert one.all_peaks(0) == res.all_peaks(b)
+    solo.close()
+    eng.close()
+
+
+def test_config5_1024_images_streamed_in_chunks():
+    """BASELINE config 5 on one GPU: 1024 images of 46x46x57 streamed in chunks of 64 through
+    the round pipeline (four skeleton-only contexts, launcher threads, two rounds in flight,
+    the gather replaced by the copy to pinned memory).  Every chunk equals a plain decode of
+    the same chunk, image order is restored, a sample is checked against the oracle."""
+    import torch
+    from poseestimation_amd import sharding, synth
+    from poseestimation_amd.predict_decode import DecodeEngine, Results
+    H = W = 368
+    CH, NCH = 64, 16
+    base_h, base_p = synth.batch(256, H, W, (1, 8), seed0=9000, paf_order='xy')
+    # 1024 images: the 256 distinct ones in four different rotations
+    heat = np.concatenate([np.roll(base_h, -37 * r, axis=0) for r in range(4)])
+    paf = np.concatenate([np.roll(base_p, -37 * r, axis=0) for r in range(4)])
+    d_heat, d_paf = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    plain = DecodeEngine(max_batch=CH, max_h=H, max_w=W, mode='D', max_pairs_per_image=40000)
+    want = [plain.decode_batch(heat[c * CH:(c + 1) * CH], paf[c * CH:(c + 1) * CH]).packed for c in range(NCH)]
+    plain.close()
+    engs = [DecodeEngine(max_batch=CH, max_h=H, max_w=W, mode='D', max_pairs_per_image=40000) for _ in range(4)]
+    for e in engs:
+        e.ctx.set_host_results(False)
+    cap = 1 << 18
+    g = sharding.SkeletonGather([e.ctx for e in engs], cap, depth=2, local=True)
+    hb = CH * 46 * 46 * 19 * 4
+    pb = CH * 46 * 46 * 38 * 4
+    got = {}
+    for rep in range(3):                 # the third pass replays recorded launch sequences
+        pending = [None, None]
+        for r in range(NCH // g.n + 2):
+            s = r % 2
+            if pending[s] is not None:
+                for j, res in enumerate(sharding.SkeletonGather.results(g.finish(s))):
+                    got[pending[s][j]] = res
+                pending[s] = None
+            chunks = list(range(r * g.n, min(NCH, (r + 1) * g.n)))
+            if not chunks:
+                continue
+            for j, c in enumerate(chunks):
+                engs[j % 4].ctx.submit(d_heat.data_ptr() + c * hb, d_paf.data_ptr() + c * pb, CH, 46, 46, H, W,
+                                       0.1, 0.05, g.slice_ptr(s, j), cap)
+            for e in engs:
+                e.ctx.flush()
+            g.start(s)
+            pending[s] = chunks
+        assert sorted(got) == list(range(NCH))
+        for c in range(NCH):
+            for key in ('part_count', 'person_count', 'status', 'peaks', 'persons'):
+                assert np.array_equal(got[c][key], want[c][key]), (rep, c, key)
+    # image order: the chunks concatenated in order are the 1024 images in order
+    allres = sharding.concat_results([got[c] for c in range(NCH)])
+    assert allres['B'] == 1024
+    r = Results(allres, engs[0].mode)
+    for b in (0, 300, 1023):
+        peaks, conns, special, subset = _oracle_image(heat[b], paf[b], 'D', H, W)
+        gio.assert_peaks_equal(r.all_peaks(b), peaks, exact_score=True)
+        gio.assert_persons_equal(r.subset(b), subset, RTOL)
+    # rotation r of the base batch sits at images 256 r ..: image 256 r + i is base image (i + 37 r) % 256
+    for rr in (1, 3):
+        for i in (0, 200):
+            np.testing.assert_array_equal(r.subset(256 * rr + i)[:, 18:], r.subset((i + 37 * rr) % 256)[:, 18:])
+    for e in engs:
+        e.close()
