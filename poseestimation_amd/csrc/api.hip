@@ -103,6 +103,7 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     CR(dev_alloc(ctx, (void**)&ctx->zero_block, ctx->zero_bytes));
     CRH(hipMemset(ctx->zero_block, 0, ctx->zero_bytes));
     ctx->zero_clean = 1;
+    CR(dev_alloc(ctx, (void**)&ctx->full_absmax, B * sizeof(float)));
     CR(dev_alloc(ctx, (void**)&ctx->fstats, 4 * sizeof(int64_t)));
     CRH(hipMemset(ctx->fstats, 0, 4 * sizeof(int64_t)));
     ctx->raw_count = ctx->zero_block;
@@ -169,7 +170,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
-                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats};
+                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats, ctx->full_absmax};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (TableSlot& t : ctx->tabs) {
@@ -327,9 +328,15 @@ extern "C" int pd_load_fullres(pd_ctx* ctx, const void* heat, int heat_dtype, in
             PD_HIP(ctx, hipMemcpyAsync(ctx->tmp_in, src, bytes, hipMemcpyHostToDevice, ctx->stream));
             dsrc = ctx->tmp_in;
         }
-        rc = pd_launch_hwc_to_planar(ctx, dsrc, dtype, C, Cdst, B, H, W, dst);
+        float* amax = nullptr;
+        if (which == 0) {  // the candidate filter of the peak stage needs a bound on the heatmaps
+            PD_HIP(ctx, hipMemsetAsync(ctx->full_absmax, 0, (size_t)B * sizeof(float), ctx->stream));
+            amax = ctx->full_absmax;
+        }
+        rc = pd_launch_hwc_to_planar(ctx, dsrc, dtype, C, Cdst, B, H, W, dst, amax);
         if (rc != PD_OK) return rc;
         if (which == 0) {
+            ctx->full_absmax_ok = 1;
             ctx->heat_f32 = dtype == PD_F32;
             ctx->have_full_heat = 1;
         } else {
@@ -382,7 +389,12 @@ extern "C" int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* he
         } else {
             for (int m = 0; m < n_scales; ++m) srcs[m] = given[m];
         }
-        rc = pd_launch_upsample_avg(ctx, n_scales, srcs, C, B, hs, ws, crop_h, crop_w, dst, H, W);
+        float* amax = nullptr;
+        if (which == 0) {
+            PD_HIP(ctx, hipMemsetAsync(ctx->full_absmax, 0, (size_t)B * sizeof(float), ctx->stream));
+            amax = ctx->full_absmax;
+        }
+        rc = pd_launch_upsample_avg(ctx, n_scales, srcs, C, B, hs, ws, crop_h, crop_w, dst, H, W, amax);
         if (rc != PD_OK) return rc;
     }
     ctx->src_kind = PD_SRC_FULLRES;
@@ -391,6 +403,7 @@ extern "C" int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* he
     ctx->W = W;
     ctx->h = ctx->w = 0;
     ctx->heat_f32 = 0;
+    ctx->full_absmax_ok = 1;
     ctx->have_full_heat = ctx->have_full_paf = 1;
     reset_results(ctx);
     return PD_OK;

@@ -171,6 +171,8 @@ struct pd_ctx {
     size_t cells_cap;
     int32_t* cand;                   // candidate list, int2 (plane, y << 16 | x)
     int32_t* cand_count;             // [B][18] candidates per plane | list length | cell counts
+    float* full_absmax;              // [max_batch] max |value| of the full-resolution heatmaps per image (rounded up)
+    int full_absmax_ok;              // full_absmax bounds the maps in full_heat
     float* absmax;                   // [B] max |heat| per image
     float* heat_planar;              // (B, 19, h, w) copy of the network heatmaps
     size_t heat_planar_cap;
@@ -315,18 +317,28 @@ int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smo
                            const int32_t* only_over, int over_limit);
 // PD_E_STATE when the geometry has no filter tables (caller falls back)
 int pd_launch_peaks_filtered(pd_ctx* ctx, double thr);
+int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr);
 int pd_launch_sort_peaks(pd_ctx* ctx);
 int pd_launch_pairs(pd_ctx* ctx, double thre2);
 int pd_launch_match(pd_ctx* ctx);
 int pd_launch_parse(pd_ctx* ctx);
 int pd_launch_pack(pd_ctx* ctx);
 int pd_launch_hwc_to_planar(pd_ctx* ctx, const void* src, int dtype, int Csrc, int Cdst, int B, int H,
-                            int W, double* dst);
+                            int W, double* dst, float* absmax);
 int pd_launch_planar_to_hwc(pd_ctx* ctx, const double* src, int C, int B, int H, int W, double* dst);
 int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W);
 void pd_host_cubic_table(int src_len, int dst_len, double scale, int32_t* ofs, float* coef);
 void pd_up8_fill(Up8* u);
 int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
-                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W);
+                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W,
+                           float* absmax);
+// max over the wavefront of a non-negative float, rounded up one ulp, folded into *dst (as bits)
+__device__ __forceinline__ void pd_wave_absmax(float m, float* dst) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    // the running maximum only grows: a stale read costs one needless atomic at most
+    if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) + 1u > __atomic_load_n((unsigned int*)dst, __ATOMIC_RELAXED))
+        atomicMax((unsigned int*)dst, __float_as_uint(m) + 1u);
+}
 MapSource pd_heat_source(const pd_ctx* ctx);
 MapSource pd_paf_source(const pd_ctx* ctx);

@@ -628,6 +628,8 @@ k_cell_filter(CellFilterArgs a) {
 
 struct VerifyArgs {
     const float* lo;  // planar copy (B, 19, h, w)
+    const double* full;  // or: full-resolution planes (B, Cfull, H, W)
+    int Cfull;
     int h, w, H, W;
     Up8 up8;
     double thr;
@@ -646,6 +648,9 @@ struct VerifyArgs {
 // X + l - 13: it forms the horizontal 4-tap sums of the (at most 8) source rows that the
 // 27 bicubic rows Y-13 .. Y+13 draw on, then the 27 vertical sums and the three y-pass
 // sums (rows Y-1, Y, Y+1); five lanes finish the x pass (centre and four neighbours).
+// FULL: the unsmoothed map is read from the float64 planes instead of being formed from the
+// network output.
+template <bool FULL>
 __global__ void __launch_bounds__(256, 2)
 k_verify(VerifyArgs a) {
     __shared__ double ypL[8][3][28];
@@ -673,7 +678,23 @@ k_verify(VerifyArgs a) {
             X = e.y & 0xffff;
             plane_total = a.cand_count[plane];  // only needed when the decision is written
         }
-        if (active && l < 27) {
+        if (FULL && active && l < 27) {
+            const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
+            const double* img = a.full + ((size_t)b * a.Cfull + part) * (size_t)H * W + pd_reflect(X + l - 13, W);
+            double u[27];
+#pragma unroll
+            for (int i = 0; i < 27; ++i) u[i] = img[(size_t)pd_reflect(Y - 13 + i, H) * W];
+            u13 = u[13];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int c = 12 + e;
+                double t = u[c] * c_gw[12];
+#pragma unroll
+                for (int d = 12; d >= 1; --d) t += (u[c - d] + u[c + d]) * c_gw[12 - d];
+                ypL[half][e][l] = t;
+            }
+        }
+        if (!FULL && active && l < 27) {
             const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
             const float* img = a.lo + ((size_t)b * PD_CH_HEAT + part) * h * w;
             // the reflected rows Y-13 .. Y+13 all lie in [max(Y-13, 0), min(Y+13, H-1)]
@@ -760,11 +781,8 @@ static int grow(pd_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
     return PD_OK;
 }
 
-int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
-    int rc = build_filter_tables(ctx);
-    if (rc != PD_OK) return rc;
-    const int B = ctx->B, H = ctx->H, W = ctx->W, h = ctx->h, w = ctx->w;
-    const int hc = (H + 7) / 8, wc = (W + 7) / 8;
+// The candidate list: room for CK = 4 * max_peaks_per_part entries per plane.
+static int ensure_candidates(pd_ctx* ctx, int* CK_out) {
     const int CK = 4 * ctx->cfg.max_peaks_per_part;
     const size_t planes_max = (size_t)ctx->cfg.max_batch * PD_N_PARTS;
     if (planes_max >= (1u << 17)) return PD_E_STATE;  // plane index is packed in 17 bits
@@ -776,6 +794,18 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         PD_HIP(ctx, hipMalloc(&ctx->cand, sizeof(int2) * planes_max * CK));
         ctx->cand_cap = CK;
     }
+    *CK_out = CK;
+    return PD_OK;
+}
+
+int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
+    int rc = build_filter_tables(ctx);
+    if (rc != PD_OK) return rc;
+    const int B = ctx->B, H = ctx->H, W = ctx->W, h = ctx->h, w = ctx->w;
+    const int hc = (H + 7) / 8, wc = (W + 7) / 8;
+    int CK = 0;
+    rc = ensure_candidates(ctx, &CK);
+    if (rc != PD_OK) return rc;
     rc = grow(ctx, (void**)&ctx->heat_planar, &ctx->heat_planar_cap, sizeof(float) * (size_t)B * PD_CH_HEAT * h * w);
     if (rc != PD_OK) return rc;
     const size_t planes = (size_t)B * PD_N_PARTS;
@@ -846,6 +876,8 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     PD_HIP(ctx, hipGetLastError());
 
     VerifyArgs v;
+    v.full = nullptr;
+    v.Cfull = 0;
     v.lo = ctx->heat_planar;
     v.h = h;
     v.w = w;
@@ -864,9 +896,251 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     int vblocks = B * 12;
     if (vblocks > 1024) vblocks = 1024;
     pd_prof_begin(ctx, PD_STAGE_VERIFY);
-    hipLaunchKernelGGL(k_verify, dim3(vblocks), dim3(256), 0, ctx->stream, v);
+    hipLaunchKernelGGL(k_verify<false>, dim3(vblocks), dim3(256), 0, ctx->stream, v);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     // planes whose candidates did not fit
+    return pd_launch_stream_exact(ctx, thr, 0, nullptr, ctx->cand_count, CK);
+}
+
+// ---------------------------------------------------------------------------------
+// Candidate filter for full-resolution float64 maps (after the multi-scale average, or
+// maps supplied by the caller): the same two-step scheme -- a float32 evaluation of the
+// smoothed map with fused multiply-adds on every pixel, tolerant NMS, exact float64
+// verification of the candidates (k_verify<true>).  With x the float64 map, M >= max |x|:
+// rounding x and the weights to float32 and two 25-term FMA chains give
+//     |S~ - S| <= 60 * 2^-24 * M  <  eps = 2^-17 * M,
+// the tolerance the network-resolution filter uses.
+//
+// One workgroup owns one (image, part, column strip) and marches down the rows; a thread owns
+// two adjacent columns, whose 25-row windows live in its registers (slot = row mod 25, made
+// static by unrolling 25 row steps): the y pass needs no memory, the y-pass row goes through
+// LDS once for the x pass, NMS of a row runs one step later from registers and the previous
+// row's LDS copy.  Streaming: every map value is read once (8 bytes per pixel).
+// ---------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define FF_NT 256
+#define FF_COLS (2 * FF_NT)
+
+static __constant__ float c_gwf[PD_GTAPS] = PD_GAUSS_WEIGHTS;
+
+struct FullFilterArgs {
+    const double* full;  // (B, Cfull, H, W)
+    int Cfull, H, W;
+    const float* absmax;  // [B] max |map value| per image (rounded up)
+    double thr;
+    int n_strips, strip_w;
+    int2* cand;
+    int cand_seg_cap;
+    int32_t* cand_count;
+    int32_t* cand_n;
+};
+
+__device__ __forceinline__ void ff_emit(const FullFilterArgs& a, int plane, int Y, int X) {
+    atomicAdd(a.cand_count + plane, 1);
+    const int seg = plane % KF_NSEG;
+    const int pos = atomicAdd(a.cand_n + seg, 1);
+    if (pos < a.cand_seg_cap)
+        a.cand[(size_t)seg * a.cand_seg_cap + pos] = make_int2(plane, (Y << 16) | X);
+    else
+        atomicOr(a.cand_count + plane, KF_OVERFLOW);  // no room: the exact kernel redoes the plane
+}
+
+struct FFState {
+    f2 s_prev1, s_prev2;  // smoothed rows y-1, y-2 of this thread's two columns
+    f2 pre0, pre1;        // map rows y+12, y+13 on their way from memory
+};
+
+// Two adjacent map values of row r (reflected at the lower edge) as float32.
+__device__ __forceinline__ f2 ff_load_row(const double* __restrict__ col, int r, int H, int W, bool act1) {
+    if (r >= H) r = 2 * H - 1 - r;
+    const double* p = col + (size_t)r * W;
+    f2 v;
+    v.x = (float)p[0];
+    v.y = act1 ? (float)p[1] : 0.f;
+    return v;
+}
+
+template <int S>
+__device__ __forceinline__ void ff_row_step(const FullFilterArgs& a, const double* __restrict__ col, f2 (&win)[25], FFState& st,
+                                            float* ybuf, float* sbuf, int y, int H, int W, int c, int xs, int xe, bool act0,
+                                            bool act1, int x0, int x1, int plane, float thr_lo, float e2) {
+    const int tid = threadIdx.x;
+    const int par = y & 1;
+    float* yrow = ybuf + par * (FF_COLS + 2 * PD_GR + 2);
+    const int li = c - xs;  // this thread's first column inside the strip
+    if (y < H && act0) {
+        // row y + 12 was requested two steps ago; row y + 14 is requested now
+        win[(S + 12) % 25] = st.pre0;
+        st.pre0 = st.pre1;
+        st.pre1 = ff_load_row(col, y + PD_GR + 2, H, W, act1);
+        f2 t = win[S] * c_gwf[12];
+#pragma unroll
+        for (int d = 12; d >= 1; --d) t = __builtin_elementwise_fma(win[(S + 25 - d) % 25] + win[(S + d) % 25], (f2)(c_gwf[12 - d]), t);
+        *(f2*)(yrow + li + PD_GR) = t;
+        // mirrored halo so the x pass reads straight offsets
+        if (xs == 0 && c < PD_GR) {
+            yrow[PD_GR - 1 - c] = t.x;
+            if (c + 1 < PD_GR) yrow[PD_GR - 2 - c] = t.y;
+        }
+        if (xe == W && c + 1 >= W - PD_GR) {
+            if (c >= W - PD_GR) yrow[(2 * W - 1 - c) - xs + PD_GR] = t.x;
+            if (act1) yrow[(2 * W - 2 - c) - xs + PD_GR] = t.y;
+        }
+    }
+    __syncthreads();
+    f2 s = (f2)(0.f);
+    if (y < H && act0) {
+        const float* p = yrow + li;  // p[k] = column c - 12 + k
+        float q[26];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) {
+            const f2 t = *(const f2*)(p + 2 * k);
+            q[2 * k] = t.x;
+            q[2 * k + 1] = t.y;
+        }
+        float sx = q[12] * c_gwf[12], sy = q[13] * c_gwf[12];
+#pragma unroll
+        for (int d = 12; d >= 1; --d) {
+            sx = fmaf(q[12 - d] + q[12 + d], c_gwf[12 - d], sx);
+            sy = fmaf(q[13 - d] + q[13 + d], c_gwf[12 - d], sy);
+        }
+        s.x = sx;
+        s.y = act1 ? sy : 0.f;
+    }
+    float* srow_w = sbuf + par * (FF_COLS + 4);
+    *(f2*)(srow_w + 2 * tid + 2) = s;  // srow[k + 2] = strip column k; srow[1] and the slot behind the strip stay 0
+    if (y >= 1) {
+        // NMS of row y - 1: centre and vertical neighbours from registers, horizontal ones from
+        // the LDS copy the previous step wrote (this step's barrier has passed)
+        const float* srow = sbuf + (par ^ 1) * (FF_COLS + 4);
+        const f2 m = st.s_prev1;
+        const f2 up = (y == 1) ? (f2)(0.f) : st.s_prev2;
+        const f2 down = (y == H) ? (f2)(0.f) : s;
+        const float left0 = (c == 0) ? 0.f : srow[2 * tid + 1];
+        const float right1 = (c + 1 >= W - 1) ? 0.f : srow[2 * tid + 4];
+        const float n0 = fmaxf(fmaxf(up.x, down.x), fmaxf(left0, (c + 1 < W) ? m.y : 0.f));
+        const float n1 = fmaxf(fmaxf(up.y, down.y), fmaxf(m.x, right1));
+        if (act0 && c >= x0 && c < x1 && m.x > thr_lo && m.x + e2 >= n0) ff_emit(a, plane, y - 1, c);
+        if (act1 && c + 1 >= x0 && c + 1 < x1 && m.y > thr_lo && m.y + e2 >= n1) ff_emit(a, plane, y - 1, c + 1);
+    }
+    st.s_prev2 = st.s_prev1;
+    st.s_prev1 = s;
+}
+
+__global__ void __launch_bounds__(FF_NT)
+k_full_filter(FullFilterArgs a) {
+    __shared__ __align__(16) float ybuf[2 * (FF_COLS + 2 * PD_GR + 2)];
+    __shared__ __align__(16) float sbuf[2 * (FF_COLS + 4)];
+    __shared__ float s_slack[2];
+    const int H = a.H, W = a.W;
+    const int b = blockIdx.z, part = blockIdx.y, strip = blockIdx.x;
+    const int plane = b * PD_N_PARTS + part;
+    const int x0 = strip * a.strip_w;
+    const int x1 = min(W, x0 + a.strip_w);
+    const int xs = max(0, x0 - (PD_GR + 1)) & ~1;
+    const int xe = min(W, x1 + (PD_GR + 1));
+    const int tid = threadIdx.x;
+    const int c = xs + 2 * tid;
+    const bool act0 = c < xe, act1 = c + 1 < xe;
+    if (tid == 0) {
+        float t, e;
+        filter_slack(a.thr, a.absmax[b], &t, &e);
+        s_slack[0] = t;
+        s_slack[1] = e;
+    }
+    for (int i = tid; i < 2 * (FF_COLS + 4); i += FF_NT) sbuf[i] = 0.f;
+    for (int i = tid; i < 2 * (FF_COLS + 2 * PD_GR + 2); i += FF_NT) ybuf[i] = 0.f;
+    __syncthreads();
+    const float thr_lo = s_slack[0], e2 = s_slack[1];
+    const double* col = a.full + ((size_t)b * a.Cfull + part) * (size_t)H * W + (act0 ? c : 0);
+    f2 win[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) win[i] = (f2)(0.f);
+    if (act0) {
+        // rows 0..11 fill slots 0..11 and, mirrored, rows -1..-12 -> slots 24..13
+#pragma unroll
+        for (int r = 0; r < PD_GR; ++r) {
+            const double* p = col + (size_t)r * W;
+            f2 v;
+            v.x = (float)p[0];
+            v.y = act1 ? (float)p[1] : 0.f;
+            win[r] = v;
+            win[24 - r] = v;
+        }
+    }
+    FFState st;
+    st.s_prev1 = (f2)(0.f);
+    st.s_prev2 = (f2)(0.f);
+    st.pre0 = st.pre1 = (f2)(0.f);
+    if (act0) {
+        st.pre0 = ff_load_row(col, PD_GR, H, W, act1);
+        st.pre1 = ff_load_row(col, PD_GR + 1, H, W, act1);
+    }
+#define FF_STEP(S)                                                                                              \
+    if (y0 + S > H) break;                                                                                      \
+    ff_row_step<S>(a, col, win, st, ybuf, sbuf, y0 + S, H, W, c, xs, xe, act0, act1, x0, x1, plane, thr_lo, e2);
+    for (int y0 = 0; y0 <= H; y0 += 25) {
+        FF_STEP(0) FF_STEP(1) FF_STEP(2) FF_STEP(3) FF_STEP(4) FF_STEP(5) FF_STEP(6) FF_STEP(7)
+        FF_STEP(8) FF_STEP(9) FF_STEP(10) FF_STEP(11) FF_STEP(12) FF_STEP(13) FF_STEP(14)
+        FF_STEP(15) FF_STEP(16) FF_STEP(17) FF_STEP(18) FF_STEP(19) FF_STEP(20) FF_STEP(21)
+        FF_STEP(22) FF_STEP(23) FF_STEP(24)
+    }
+#undef FF_STEP
+}
+
+// Peak stage on the full-resolution float64 heatmaps the context holds (ctx->full_absmax must
+// bound them): candidate filter, exact verification, exact kernel for overflowing planes.
+int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr) {
+    const int B = ctx->B, H = ctx->H, W = ctx->W;
+    if (H >= 65536 || W >= 65536) return PD_E_STATE;  // candidates pack (y, x) in 16 bits each
+    int CK = 0;
+    int rc = ensure_candidates(ctx, &CK);
+    if (rc != PD_OK) return rc;
+    const size_t planes = (size_t)B * PD_N_PARTS;
+    int32_t* counters = ctx->cand_count + planes;
+    FullFilterArgs f;
+    f.full = ctx->full_heat;
+    f.Cfull = PD_CH_HEAT;
+    f.H = H;
+    f.W = W;
+    f.absmax = ctx->full_absmax;
+    f.thr = thr;
+    // strips: owned columns plus 13 either side (and one for the even start) within 2 * FF_NT columns
+    const int halo = 2 * (PD_GR + 1) + 1;
+    f.n_strips = W + 1 <= FF_COLS ? 1 : (W + (FF_COLS - halo) - 1) / (FF_COLS - halo);
+    f.strip_w = (W + f.n_strips - 1) / f.n_strips;
+    f.cand = (int2*)ctx->cand;
+    f.cand_seg_cap = (int)(planes * CK / KF_NSEG);
+    f.cand_count = ctx->cand_count;
+    f.cand_n = counters;
+    pd_prof_begin(ctx, PD_STAGE_FILTER);
+    hipLaunchKernelGGL(k_full_filter, dim3(f.n_strips, PD_N_PARTS, B), dim3(FF_NT), 0, ctx->stream, f);
+    pd_prof_end(ctx);
+    PD_HIP(ctx, hipGetLastError());
+
+    VerifyArgs v;
+    v.lo = nullptr;
+    v.full = ctx->full_heat;
+    v.Cfull = PD_CH_HEAT;
+    v.h = v.w = 0;
+    v.H = H;
+    v.W = W;
+    pd_up8_fill(&v.up8);
+    v.thr = thr;
+    v.cand = (const int2*)ctx->cand;
+    v.cand_seg_cap = f.cand_seg_cap;
+    v.cand_count = ctx->cand_count;
+    v.cand_n = counters;
+    v.CK = CK;
+    v.raw = ctx->raw;
+    v.raw_count = ctx->raw_count;
+    v.PK = ctx->cfg.max_peaks_per_part;
+    int vblocks = B * 12;
+    if (vblocks > 1024) vblocks = 1024;
+    pd_prof_begin(ctx, PD_STAGE_VERIFY);
+    hipLaunchKernelGGL(k_verify<true>, dim3(vblocks), dim3(256), 0, ctx->stream, v);
+    pd_prof_end(ctx);
+    PD_HIP(ctx, hipGetLastError());
     return pd_launch_stream_exact(ctx, thr, 0, nullptr, ctx->cand_count, CK);
 }

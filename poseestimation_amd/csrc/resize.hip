@@ -105,14 +105,17 @@ int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W) {
 }
 
 __global__ void k_hwc_to_planar(const void* __restrict__ src, int dtype, int Csrc, int Cdst, int H, int W,
-                                double* __restrict__ dst) {
+                                double* __restrict__ dst, float* absmax) {
     const size_t n = (size_t)H * W;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const int ch = blockIdx.y, b = blockIdx.z;
-    const size_t s = ((size_t)b * n + i) * Csrc + ch;
-    const double v = dtype == PD_F32 ? (double)((const float*)src)[s] : ((const double*)src)[s];
-    dst[((size_t)b * Cdst + ch) * n + i] = v;
+    double v = 0.0;
+    if (i < n) {
+        const size_t s = ((size_t)b * n + i) * Csrc + ch;
+        v = dtype == PD_F32 ? (double)((const float*)src)[s] : ((const double*)src)[s];
+        dst[((size_t)b * Cdst + ch) * n + i] = v;
+    }
+    if (absmax) pd_wave_absmax((float)fabs(v), absmax + b);
 }
 
 __global__ void k_planar_to_hwc(const double* __restrict__ src, int C, int H, int W, double* __restrict__ dst) {
@@ -146,14 +149,25 @@ struct AvgArgs {
     float n_div, n_rcp;   // number of scales; its reciprocal when that is exact (a power of two)
     Up8 up8;
     double* dst;          // planar (B, C, H, W)
+    float* absmax;        // [B] or NULL: receives max |output| per image (bits of a non-negative float)
 };
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 #define FT_TW 32        // output tile of a workgroup: FT_TW x FT_TH = 256 pixels
 #define FT_TH 8
 #define FT_CH 4         // channels per workgroup: they are adjacent in the (h, w, C) source, one 16-byte load
-#define FT_PATCH 1536   // x8-map values per channel staged in LDS (a downscale up to about 2.1)
-#define FT_HSUM 768     // horizontal sums per channel staged in LDS
+#define FT_PATCH 1408   // x8-map pixels (four channels each) staged in LDS: a downscale up to about 2.1
+#define FT_HSUM 704     // horizontal sums (four channels each) staged in LDS
+#define FT_SRC 192      // source pixels (four channels each) staged in LDS
+
+// floor(e / d) for 0 <= e, e * d < 2^20, as a multiplication: m = ceil(2^20 / d).
+__device__ __forceinline__ int div_magic(int d) { return ((1 << 20) + d - 1) / d; }
+__device__ __forceinline__ int div_by(int e, int m) { return (int)(((unsigned)e * (unsigned)m) >> 20); }
+
+__device__ __forceinline__ float4 tap4v(const float4& s0, const float4& s1, const float4& s2, const float4& s3, const float4& c) {
+    return make_float4(((s0.x * c.x + s1.x * c.y) + s2.x * c.z) + s3.x * c.w, ((s0.y * c.x + s1.y * c.y) + s2.y * c.z) + s3.y * c.w,
+                       ((s0.z * c.x + s1.z * c.y) + s2.z * c.z) + s3.z * c.w, ((s0.w * c.x + s1.w * c.y) + s2.w * c.z) + s3.w * c.w);
+}
 
 // v / n as the reference's float32 division rounds it; for a power of two the product with
 // the reciprocal is the same number.
@@ -209,8 +223,10 @@ __device__ __forceinline__ float4 up8_at(const float* img, int hs, int ws, int C
 template <bool POW2, bool DIRECT>
 __global__ void __launch_bounds__(256, DIRECT ? 1 : 4)
 k_resize_fused(AvgArgs a) {
-    __shared__ __align__(16) float patch[FT_CH][FT_PATCH];
-    __shared__ __align__(16) float hsum[FT_CH][FT_HSUM];
+    // pixels of four channels each (a float4), so that every tap is one 16-byte LDS access
+    __shared__ float4 patch[FT_PATCH];
+    __shared__ float4 hsum[FT_HSUM];
+    __shared__ float4 srcp[FT_SRC];
     __shared__ float4 s_up[8];
     const int tid = threadIdx.x;
     if (tid < 8) s_up[tid] = make_float4(a.up8.c[tid][0], a.up8.c[tid][1], a.up8.c[tid][2], a.up8.c[tid][3]);
@@ -251,81 +267,79 @@ k_resize_fused(AvgArgs a) {
         }
         const int j_lo = pd_up8_ofs(r_lo);                         // first source row (unclamped)
         const int nj = pd_up8_ofs(r_lo + ph - 1) + 3 - j_lo + 1;   // source rows the patch draws on
-        const bool staged = !DIRECT || (ph * pw <= FT_PATCH && nj * pw <= FT_HSUM);
+        // source columns the patch draws on, after clamping to the map
+        const int i_lo = pd_clampi(pd_up8_ofs(c_lo), 0, sc.ws - 1);
+        const int ni = pd_clampi(pd_up8_ofs(c_lo + pw - 1) + 3, 0, sc.ws - 1) - i_lo + 1;
+        const bool staged = !DIRECT || (ph * pw <= FT_PATCH && nj * pw <= FT_HSUM && nj * ni <= FT_SRC);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (staged) {
+            // 0: the source pixels, element e = source row jj (clamped to the map), column ii
+            {
+                const int mg = div_magic(ni);
+                for (int e = tid; e < nj * ni; e += 256) {
+                    const int jj = div_by(e, mg), ii = e - jj * ni;
+                    const unsigned off = (unsigned)((pd_clampi(j_lo + jj, 0, sc.hs - 1) * sc.ws + i_lo + ii) * a.C);
+                    srcp[e] = load_channels(img + off, nch);
+                }
+            }
+            __syncthreads();
             // A: horizontal sums, element e = source row jj, patch column c
+            const int mw = div_magic(pw);
             for (int e = tid; e < nj * pw; e += 256) {
-                const int jj = e / pw, c = e - jj * pw;
-                const float4 hsv = hsum_at(img, sc.ws, a.C, pd_clampi(j_lo + jj, 0, sc.hs - 1), c_lo + c, nch, s_up);
-                hsum[0][e] = hsv.x;
-                hsum[1][e] = hsv.y;
-                hsum[2][e] = hsv.z;
-                hsum[3][e] = hsv.w;
+                const int jj = div_by(e, mw), c = e - jj * pw;
+                const int col = c_lo + c;
+                const int x0 = pd_up8_ofs(col);
+                const float4* row = srcp + jj * ni - i_lo;
+                const int hi = sc.ws - 1;
+                hsum[e] = tap4v(row[pd_clampi(x0, 0, hi)], row[pd_clampi(x0 + 1, 0, hi)], row[pd_clampi(x0 + 2, 0, hi)],
+                                row[pd_clampi(x0 + 3, 0, hi)], s_up[pd_up8_phase(col)]);
             }
             __syncthreads();
             // B: the patch.  A thread walks down a run of rows of one column and keeps the four
             // horizontal sums in use in registers (the first tap row advances every eighth row).
             const int G = max(1, 256 / pw), rpg = (ph + G - 1) / G;
             for (int it = tid; it < G * pw; it += 256) {
-                const int g = it / pw, c = it - g * pw;
+                const int g = div_by(it, mw), c = it - g * pw;
                 const int r1 = min(ph, (g + 1) * rpg);
                 int cur = -0x40000000;
-                float hv[4][FT_CH];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int q = 0; q < FT_CH; ++q) hv[k][q] = 0.f;
+                float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0, h2 = h0, h3 = h0;
                 for (int r = g * rpg; r < r1; ++r) {
                     const int rabs = r_lo + r;
                     const int y0 = pd_up8_ofs(rabs) - j_lo;
-                    if (y0 == cur + 1) {
-#pragma unroll
-                        for (int q = 0; q < FT_CH; ++q) {
-                            hv[0][q] = hv[1][q];
-                            hv[1][q] = hv[2][q];
-                            hv[2][q] = hv[3][q];
-                            hv[3][q] = hsum[q][(y0 + 3) * pw + c];
+                    if (y0 != cur) {
+                        const float4* col = hsum + y0 * pw + c;
+                        if (y0 == cur + 1) {
+                            h0 = h1;
+                            h1 = h2;
+                            h2 = h3;
+                        } else {
+                            h0 = col[0];
+                            h1 = col[pw];
+                            h2 = col[2 * pw];
                         }
-                    } else if (y0 != cur) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-#pragma unroll
-                            for (int q = 0; q < FT_CH; ++q) hv[k][q] = hsum[q][(y0 + k) * pw + c];
+                        h3 = col[3 * pw];
+                        cur = y0;
                     }
-                    cur = y0;
-                    const float4 w = s_up[pd_up8_phase(rabs)];
-#pragma unroll
-                    for (int q = 0; q < FT_CH; ++q) patch[q][r * pw + c] = tap4(hv[0][q], hv[1][q], hv[2][q], hv[3][q], w);
+                    patch[r * pw + c] = tap4v(h0, h1, h2, h3, s_up[pd_up8_phase(rabs)]);
                 }
             }
             __syncthreads();
             // C: the second resize from the patch
             if (sc.identity) {
-                const int o = (Y - r_lo) * pw + (X - c_lo);
-                v = make_float4(patch[0][o], patch[1][o], patch[2][o], patch[3][o]);
+                v = patch[(Y - r_lo) * pw + (X - c_lo)];
             } else {
                 const int x0 = sc.tx.ofs[X], y0 = sc.ty.ofs[Y];
                 const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)X);
                 const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Y);
                 const int xi0 = pd_clampi(x0, 0, sc.crop_w - 1) - c_lo, xi1 = pd_clampi(x0 + 1, 0, sc.crop_w - 1) - c_lo,
                           xi2 = pd_clampi(x0 + 2, 0, sc.crop_w - 1) - c_lo, xi3 = pd_clampi(x0 + 3, 0, sc.crop_w - 1) - c_lo;
-                int ro[4];
+                float4 hvv[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ro[k] = (pd_clampi(y0 + k, 0, sc.crop_h - 1) - r_lo) * pw;
-                float o4[FT_CH];
-#pragma unroll
-                for (int q = 0; q < FT_CH; ++q) {
-                    const float* p = patch[q];
-                    float hvv[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float* row = p + ro[k];
-                        hvv[k] = tap4(row[xi0], row[xi1], row[xi2], row[xi3], ac);
-                    }
-                    o4[q] = tap4(hvv[0], hvv[1], hvv[2], hvv[3], bc);
+                for (int k = 0; k < 4; ++k) {
+                    const float4* row = patch + (pd_clampi(y0 + k, 0, sc.crop_h - 1) - r_lo) * pw;
+                    hvv[k] = tap4v(row[xi0], row[xi1], row[xi2], row[xi3], ac);
                 }
-                v = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                v = tap4v(hvv[0], hvv[1], hvv[2], hvv[3], bc);
             }
         } else if (DIRECT) {
             // a patch too large to stage (a strong downscale): every tap of the second resize is
@@ -366,6 +380,13 @@ k_resize_fused(AvgArgs a) {
         // no barrier here: the next scale's pass A writes hsum only (every thread is past
         // this scale's pass B), and its pass B writes the patch behind a barrier of its own
     }
+    if (a.absmax) {
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < FT_CH; ++c)
+            if (inside && c < nch) mx = fmaxf(mx, (float)fabs(acc[c]));
+        pd_wave_absmax(mx, a.absmax + b);
+    }
     if (!inside) return;
     double* out = a.dst + ((size_t)b * a.C + ch0) * n + (size_t)Y * a.W + X;
 #pragma unroll
@@ -381,7 +402,7 @@ static bool patches_fit(int crop_h, int crop_w, int H, int W) {
     pd_host_cubic_table(crop_h, H, -1.0, oy.data(), cy.data());
     pd_host_cubic_table(crop_w, W, -1.0, ox.data(), cx.data());
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    int max_ph = 0, max_pw = 0, max_nj = 0;
+    int max_ph = 0, max_pw = 0, max_nj = 0, max_ni = 0;
     for (int Y0 = 0; Y0 < H; Y0 += FT_TH) {
         const int Yl = std::min(Y0 + FT_TH - 1, H - 1);
         const int r_lo = clampi(oy[Y0], 0, crop_h - 1);
@@ -393,16 +414,20 @@ static bool patches_fit(int crop_h, int crop_w, int H, int W) {
     for (int X0 = 0; X0 < W; X0 += FT_TW) {
         const int Xl = std::min(X0 + FT_TW - 1, W - 1);
         const int c_lo = clampi(ox[X0], 0, crop_w - 1);
-        max_pw = std::max(max_pw, clampi(ox[Xl] + 3, 0, crop_w - 1) - c_lo + 1);
+        const int pw = clampi(ox[Xl] + 3, 0, crop_w - 1) - c_lo + 1;
+        max_pw = std::max(max_pw, pw);
+        max_ni = std::max(max_ni, pd_up8_ofs(c_lo + pw - 1) + 3 - pd_up8_ofs(c_lo) + 1);
     }
-    return max_ph * max_pw <= FT_PATCH && max_nj * max_pw <= FT_HSUM;
+    return max_ph * max_pw <= FT_PATCH && max_nj * max_pw <= FT_HSUM && max_nj * max_ni <= FT_SRC;
 }
 
 // All scales of one map family (C = 19 or 38): srcs[m] is (B, hs[m], ws[m], C) on the device.
 int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
-                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W) {
+                           const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W,
+                           float* absmax) {
     AvgArgs a;
     memset(&a, 0, sizeof(a));
+    a.absmax = absmax;
     pd_up8_fill(&a.up8);
     bool direct = false;
     for (int m = 0; m < n_scales; ++m) {
@@ -446,12 +471,12 @@ int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, 
 }
 
 int pd_launch_hwc_to_planar(pd_ctx* ctx, const void* src, int dtype, int Csrc, int Cdst, int B, int H,
-                            int W, double* dst) {
+                            int W, double* dst, float* absmax) {
     const size_t n = (size_t)H * W;
     const int nch = Csrc < Cdst ? Csrc : Cdst;
     pd_prof_begin(ctx, PD_STAGE_RESIZE);
     hipLaunchKernelGGL(k_hwc_to_planar, dim3((unsigned)((n + 255) / 256), nch, B), dim3(256), 0, ctx->stream, src,
-                       dtype, Csrc, Cdst, H, W, dst);
+                       dtype, Csrc, Cdst, H, W, dst, absmax);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;

@@ -300,6 +300,12 @@ int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
         int rc = pd_launch_peaks_filtered(ctx, thr);
         if (rc != PD_E_STATE) return rc;
     }
+    if (ctx->impl == PD_IMPL_FAST && !small && src.kind == PD_SRC_FULLRES && !f32mode && ctx->full_absmax_ok &&
+        dbg_smoothed == nullptr) {
+        // the same scheme on the float64 planes the context holds
+        int rc = pd_launch_peaks_filtered_full(ctx, thr);
+        if (rc != PD_E_STATE) return rc;
+    }
     if (ctx->impl != PD_IMPL_SIMPLE && !small) return pd_launch_stream_exact(ctx, thr, f32mode, dbg_smoothed, nullptr, 0);
     // simple path: materialise the 18 planes, filter axis 0 then axis 1, NMS
     const size_t n = (size_t)H * W;

@@ -213,6 +213,73 @@ def test_candidate_filter_equals_exact_kernel(pdec, kind, thr, pk, h, w, H, W):
         assert out[0]['peaks'].size > 0
 
 
+def _fullres_case(kind, rng, H, W):
+    from scipy.ndimage import gaussian_filter
+    x = np.zeros((2, H, W, 19), np.float64)
+    if kind == 'noise':            # a peak every few pixels, values of both signs
+        x[:] = rng.randn(2, H, W, 19) * 0.5
+    elif kind == 'big':
+        x[:] = rng.randn(2, H, W, 19) * 300.0
+    elif kind == 'blobs':          # smooth maps with a few maxima, like real averaged heatmaps
+        for b in range(2):
+            for c in range(19):
+                x[b, :, :, c] = gaussian_filter(rng.randn(H, W), 9.0) * 12.0
+    elif kind == 'plateau':        # exact ties between neighbours
+        x[:, 5:40, 8:60, :] = 0.75
+        x[1, H - 20:, W - 30:, 3] = 1.0
+    elif kind.startswith('ridge'):  # near-flat ridges the float32 pass cannot separate
+        yy = np.arange(H)[:, None] / H
+        xx = np.arange(W)[None, :] / W
+        for c in range(19):
+            x[:, :, :, c] = 0.6 * np.exp(-((yy - 0.5 - 0.01 * c) ** 2) / 0.02) * (1 + 1e-9 * xx)
+    elif kind == 'tiny_values':
+        x[:] = rng.rand(2, H, W, 19) * 1e-9 + 0.2
+    elif kind == 'edges':          # maxima on the first / last rows and columns
+        x[:, 0, :, :] = 1.0 + 0.1 * rng.rand(2, W, 19)
+        x[:, -1, :, :] = 1.0 + 0.1 * rng.rand(2, W, 19)
+        x[:, :, 0, :] += 1.0 + 0.1 * rng.rand(2, H, 19)
+        x[:, :, -1, :] += 1.0 + 0.1 * rng.rand(2, H, 19)
+    return x
+
+
+@pytest.mark.parametrize('kind,thr,pk', [('noise', 0.1, 8192), ('noise', -0.2, 8192), ('big', 0.1, 8192),
+                                         ('blobs', 0.1, 256), ('plateau', 0.1, 4096), ('ridge', 0.1, 4096),
+                                         ('ridge_small_lists', 0.1, 64), ('tiny_values', 0.1, 4096),
+                                         ('edges', 0.1, 4096)])
+@pytest.mark.parametrize('H,W', [(368, 368), (26, 26), (61, 511), (47, 512), (90, 513), (33, 1001)])
+def test_fullres_candidate_filter_equals_exact_kernel(kind, thr, pk, H, W):
+    """Full-resolution float64 maps handed in by the caller (or left by the multi-scale
+    average): the float32 filter over every pixel + exact verification (impl 0) against the
+    exact float64 kernel (impl 2), at widths of one, two and three column strips, odd and
+    even, on inputs built to stress the tolerance and the list capacities."""
+    from poseestimation_amd import _ffi
+    if kind == 'noise' and H * W > 40000:
+        pytest.skip('more peaks than any list holds; covered at the smaller sizes')
+    rng = np.random.RandomState(78)
+    x = _fullres_case(kind, rng, H, W)
+    out = []
+    for impl in (2, 0):
+        with _ffi.Context(max_batch=2, max_h=H, max_w=W, max_peaks_per_part=pk, max_persons=8,
+                          max_pairs_per_image=64) as ctx:
+            ctx.set_impl(impl)
+            ctx.load_fullres(x, None, 2, H, W)
+            ctx.peaks(thr)
+            ctx.pack()
+            try:
+                out.append(ctx.fetch())
+            except _ffi.DecodeOverflow:
+                assert impl == 2, 'the filtered path overflowed where the exact one did not'
+                pytest.skip("more true peaks than this case's lists hold")
+            if impl == 0:
+                stats = ctx.filter_stats()
+    np.testing.assert_array_equal(out[0]['part_count'], out[1]['part_count'])
+    assert np.array_equal(out[0]['peaks'], out[1]['peaks'])
+    if kind in ('noise', 'blobs', 'plateau', 'ridge', 'edges'):
+        assert out[0]['peaks'].size > 0
+    if kind == 'blobs':
+        assert stats['planes_exact'] == 0 and stats['candidates'] > 0
+
+
 @pytest.mark.parametrize('profile', [False, True])
 def test_device_resident_replay_follows_the_data(pdec, profile):
     """Device-resident inputs go through the captured launch graph from the third call
