@@ -283,6 +283,83 @@ int pd_decode_batch_static(const float* heat, const float* paf, int B, int h, in
                            double thre1, double thre2, int mode, void* out, uint64_t out_capacity,
                            void* stream);
 
+/* The stray debug output of utils/postprocess.py:224-225 -- print(connection, len(found))
+ * for every connection of limb 18 -- is not produced by the library; with recording on
+ * (enable != 0) pd_parse runs the table form of the parser and notes len(found) of every
+ * limb-18 connection, and a call with out != NULL copies those numbers out
+ * ([max_batch][max_peaks_per_part] int32, connection order) so that the caller can print the
+ * reference's lines.  enable = 0 switches recording off again. */
+int pd_debug_found(pd_ctx* ctx, int enable, int32_t* out);
+
+/* ---- next to the decode: its consumers and the step before it ---- */
+
+/* Person rows -> COCO keypoint rows, the loop of evaluate.py:44-74 over a decoded batch,
+ * computed on the device from the peaks and person rows the context holds.  Row r (image-
+ * major, then in person-row order) is person r: keypoints[r][k] = (c0, c1, 1) of the peak
+ * that person[cfg.coco_to_ours[k]] names (cfgs/config_vgg19.py:48), i.e. the first two
+ * columns of predict.py:179's `candidate` -- (x, y) in mode D, (y, x) in mode P -- or
+ * (0, 0, 0) where the part is missing (evaluate.py:53-54); scores[r] = person[-2]
+ * (evaluate.py:45); image_index[r] = the image of the batch.  keypoints is
+ * [capacity][17][3] float64; *n_rows receives the number of rows; more rows than capacity
+ * -> PD_E_OVERFLOW with *n_rows set and nothing copied.  Output pointers are host
+ * addresses; any may be NULL.  Waits for the context's stream. */
+#define PD_COCO_KEYPOINTS 17
+int pd_coco_rows(pd_ctx* ctx, double* keypoints, double* scores, int32_t* image_index,
+                 int64_t capacity, int64_t* n_rows);
+
+/* The image side of the scale loop, predict.py:56-57:
+ *   scale_img = cv2.resize(img, (0, 0), fx=scale, fy=scale, interpolation=cv2.INTER_CUBIC)
+ *   scale_img_padded, pad = pad_right_down_corner(scale_img, stride, pad_value)
+ * img is (h, w, channels) PD_U8 or PD_F32, channels <= 4; out is (out_h, out_w, channels)
+ * PD_F32 or PD_U8 with out_h / out_w = the resized size (h * scale, w * scale rounded half
+ * to even) padded below / right to a multiple of stride -- pd_image_resize_shape computes
+ * them and the pad list entries pad[2], pad[3].  The cubic is evaluated in float32 with the
+ * arithmetic of pd_upsample_avg; PD_U8 output rounds half to even and saturates.  (OpenCV's
+ * own 8-bit path is a fixed-point variant whose last bit depends on the build; there is no
+ * fixture for it.)  mem says where img and out live. */
+enum { PD_U8 = 2 };
+int pd_image_resize_shape(int h, int w, double scale, int stride, int32_t* resized_h,
+                          int32_t* resized_w, int32_t* pad_down, int32_t* pad_right);
+int pd_image_resize_pad(pd_ctx* ctx, const void* img, int img_dtype, int h, int w, int channels,
+                        double scale, int stride, double pad_value, void* out, int out_dtype,
+                        int out_h, int out_w, int mem);
+
+/* visualize(), predict.py:256-307, as a per-pixel kernel.  img is (H, W, 3) uint8 on the
+ * host.  circles[n][3] = (x, y, colour index): the filled radius-4 discs of predict.py:272
+ * in draw order; part_out receives cv2.addWeighted(img, 0.3, canvas, 0.7, 0)
+ * (predict.py:277, part.jpg).  ellipses[m][6] = (cx, cy, a, b, angle in whole degrees,
+ * colour index): the arguments predict.py:297 hands to cv2.ellipse2Poly for every (limb,
+ * person), in draw order; each is filled and blended 0.4 / 0.6 into the canvas
+ * (predict.py:298-299); final_out receives the canvas (final.jpg).  Colours are
+ * predict.py:258-260's table.  Shapes are evaluated analytically per pixel; OpenCV
+ * rasterises polygons, so outlines may differ by a pixel (no fixture exists to pin them).
+ * Either output may be NULL. */
+int pd_render(pd_ctx* ctx, const uint8_t* img, int H, int W, int n_circles, const int32_t* circles,
+              int n_ellipses, const int32_t* ellipses, uint8_t* part_out, uint8_t* final_out);
+
+/* ---- multi-GPU collect without a framework in the process ----
+ * No counterpart in the reference (single process).  A communicator wraps RCCL, which is
+ * loaded at run time (PD_RCCL_LIBRARY names the file; default librccl.so.1).  One rank
+ * makes the 128-byte id with pd_comm_unique_id and hands it to the others by any means;
+ * every rank then calls pd_comm_create(id, world, rank, device). */
+typedef struct pd_comm pd_comm;
+int pd_comm_unique_id(void* id128);
+int pd_comm_create(const void* id128, int world, int rank, int device_id, pd_comm** out);
+int pd_comm_destroy(pd_comm* comm);
+const char* pd_comm_last_error(pd_comm* comm);
+
+/* Collects the skeleton buffers (pd_set_skeleton_buffer) of every rank's n_ctx contexts on
+ * rank `root`: an all-gather of the byte counts, then grouped sends / receives of exactly
+ * those bytes, then one copy to recv_host.  On the root, recv_host receives the buffers
+ * back to back (each starting 16-byte aligned) in rank-major, then context order -- the
+ * image order of a batch sharded in contiguous blocks -- and sizes[rank * n_ctx + i]
+ * their lengths; *total_bytes is the room they take (also when recv_capacity is too
+ * small: PD_E_OVERFLOW, nothing received... every rank must then call again).  Waits for
+ * the contexts' streams first and for the collect before it returns; n_ctx <= 16 and
+ * equal on all ranks. */
+int pd_gather(pd_comm* comm, pd_ctx* const* ctxs, int n_ctx, int root, void* recv_host,
+              uint64_t recv_capacity, uint64_t* sizes, uint64_t* total_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -376,3 +376,80 @@ def coco_records(candidate, subset, image_id, coco_to_ours):
         out.append({"image_id": image_id, "category_id": 1,
                     "keypoints": list(kp.reshape(-1)), "score": person[-2]})
     return out
+
+
+# ----------------------------------------------------------------------------
+# image side of the scale loop (predict.py:56-57)  -- UNPINNED (cv2 absent)
+# ----------------------------------------------------------------------------
+
+def image_resize_pad(img, scale, stride=8, pad_value=128, out_dtype=None):
+    """cv2.resize(img, (0, 0), fx=scale, fy=scale, INTER_CUBIC) evaluated in float32 (the
+    restatement above), uint8 results rounded half to even and saturated; then
+    pad_right_down_corner (predict.py:19-32).  Returns (img_padded, pad)."""
+    img = np.asarray(img)
+    out_dtype = np.dtype(out_dtype or img.dtype)
+    res = resize_cubic(img.astype(np.float32), fx=scale, fy=scale)
+    down, right = pad_amounts(res.shape[0], res.shape[1], stride)
+    out = np.full((res.shape[0] + down, res.shape[1] + right, res.shape[2]), np.float32(pad_value), np.float32)
+    out[:res.shape[0], :res.shape[1]] = res
+    if out_dtype == np.uint8:
+        out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return out, [0, 0, down, right]
+
+
+# ----------------------------------------------------------------------------
+# visualize (predict.py:256-307)  -- UNPINNED: analytic shapes, not cv2's rasteriser
+# ----------------------------------------------------------------------------
+
+COLORS = np.array([[255, 0, 0], [255, 85, 0], [255, 170, 0], [255, 255, 0], [170, 255, 0], [85, 255, 0], [0, 255, 0],
+                   [0, 255, 85], [0, 255, 170], [0, 255, 255], [0, 170, 255], [0, 85, 255], [0, 0, 255], [85, 0, 255],
+                   [170, 0, 255], [255, 0, 255], [255, 0, 170], [255, 0, 85]], np.float32)    # predict.py:258-260
+
+
+def _add_weighted(a, wa, b, wb):
+    """cv2.addWeighted on 8-bit images: float32 arithmetic, rounded half to even, saturated."""
+    return np.clip(np.rint(a * np.float32(wa) + b * np.float32(wb)), 0, 255).astype(np.float32)
+
+
+def visualize(img, candidate, all_peaks, subset, limb_seq=None):
+    """predict.py:256-307 with per-pixel analytic shapes: discs dx^2 + dy^2 <= r^2 + r (r = 4)
+    for cv2.circle, the ellipse (centre, semi-axes, whole-degree angle) handed to
+    cv2.ellipse2Poly for the filled polygon.  Returns (part.jpg image, final.jpg image)."""
+    import math
+    if limb_seq is None:
+        limb_seq = list(zip(LIMB_FROM, LIMB_TO))
+    img = np.asarray(img, np.uint8)
+    H, W = img.shape[:2]
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = img.astype(np.float32)
+    canvas = base.copy()
+    for i in range(18):
+        for p in all_peaks[i]:
+            dx, dy = xx - int(p[0]), yy - int(p[1])                         # predict.py:272
+            canvas[dx * dx + dy * dy <= 4 * 4 + 4] = COLORS[i]
+    part = _add_weighted(base, 0.3, canvas, 0.7)                            # predict.py:277
+    candidate = np.asarray(candidate, np.float64).reshape(-1, 4)
+    for i in range(19):
+        if i == 9 or i == 13:
+            continue
+        for n in range(len(subset)):
+            index = np.asarray(subset[n])[np.array(limb_seq[i])]
+            if -1 in index:
+                continue
+            Y = candidate[index.astype(int), 0]
+            X = candidate[index.astype(int), 1]
+            mX, mY = np.mean(X), np.mean(Y)
+            length = ((X[0] - X[1]) ** 2 + (Y[0] - Y[1]) ** 2) ** 0.5
+            angle = math.degrees(math.atan2(X[0] - X[1], Y[0] - Y[1]))
+            cx, cy, a, b, ang = int(mY), int(mX), int(length / 2), 4, int(angle)   # predict.py:297
+            a = np.float32(a if a >= 1 else 0.5)
+            b = np.float32(b)
+            co = np.float32(math.cos(ang * (math.pi / 180.0)))
+            si = np.float32(math.sin(ang * (math.pi / 180.0)))
+            dx = (xx - cx).astype(np.float32)
+            dy = (yy - cy).astype(np.float32)
+            u = (dx * co + dy * si) / a
+            v = (dy * co - dx * si) / b
+            inside = u * u + v * v <= np.float32(1.0)
+            canvas[inside] = _add_weighted(canvas[inside], 0.4, COLORS[i % 18][None, :], 0.6)   # predict.py:298-299
+    return part.astype(np.uint8), canvas.astype(np.uint8)

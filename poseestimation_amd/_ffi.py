@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('PD_LIBRARY') or os.path.join(_HERE, 'libposedecode.so
 PD_OK, PD_E_INVALID, PD_E_HIP, PD_E_OVERFLOW, PD_E_INDEX, PD_E_STATE = 0, -1, -2, -3, -4, -5
 MODE_P, MODE_D = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-F32, F64 = 0, 1
+F32, F64, U8 = 0, 1, 2
 IMPL_FAST, IMPL_SIMPLE, IMPL_STREAM = 0, 1, 2
 
 EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mode', 'pd_set_impl',
@@ -22,7 +22,8 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
            'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay', 'pd_set_host_results',
-           'pd_decode_batch_static']
+           'pd_decode_batch_static', 'pd_coco_rows', 'pd_image_resize_shape', 'pd_image_resize_pad', 'pd_render',
+           'pd_debug_found', 'pd_comm_unique_id', 'pd_comm_create', 'pd_comm_destroy', 'pd_comm_last_error', 'pd_gather']
 
 STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells', 'filter_border']
 
@@ -131,9 +132,21 @@ def lib():
     L.pd_set_host_results.argtypes = [vp, i32]
     L.pd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.pd_decode_batch_static.argtypes = [vp, vp, i32, i32, i32, i32, i32, dbl, dbl, i32, vp, C.c_uint64, vp]
+    i32p = C.POINTER(C.c_int32)
+    L.pd_coco_rows.argtypes = [vp, vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.pd_image_resize_shape.argtypes = [i32, i32, dbl, i32, i32p, i32p, i32p, i32p]
+    L.pd_image_resize_pad.argtypes = [vp, vp, i32, i32, i32, i32, dbl, i32, dbl, vp, i32, i32, i32, i32]
+    L.pd_render.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
+    L.pd_debug_found.argtypes = [vp, i32, vp]
+    L.pd_comm_unique_id.argtypes = [vp]
+    L.pd_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.pd_comm_destroy.argtypes = [vp]
+    L.pd_comm_last_error.argtypes = [vp]
+    L.pd_comm_last_error.restype = C.c_char_p
+    L.pd_gather.argtypes = [vp, C.POINTER(vp), i32, i32, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ('pd_last_error', 'pd_version', 'pd_stream'):
+        if name not in ('pd_last_error', 'pd_version', 'pd_stream', 'pd_comm_last_error'):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -363,7 +376,133 @@ class Context:
         self.check(self.L.pd_filter_stats(self._h, out))
         return dict(candidates=out[0], cells_interior=out[1], cells_border=out[2], planes_exact=out[3])
 
+    def debug_found(self, enable=True, read=False):
+        """Recording of ``len(found)`` per limb-18 connection (utils/postprocess.py:224-225);
+        ``read=True`` returns the (max_batch, max_peaks_per_part) int32 table first."""
+        out = None
+        if read:
+            out = np.zeros((self.cfg.max_batch, self.cfg.max_peaks_per_part), np.int32)
+        self.check(self.L.pd_debug_found(self._h, 1 if enable else 0, _ptr(out)))
+        return out
+
+    def coco_rows(self):
+        """evaluate.py:44-74 on the device: ``(keypoints (n, 17, 3), scores (n,), image_index (n,))``
+        for the person rows of the decode the context holds."""
+        cap = max(1, int(self.cfg.max_batch) * int(self.cfg.max_persons))
+        n = C.c_int64()
+        # the row count is only known on the device: ask first with no room, then fetch
+        rc = self.L.pd_coco_rows(self._h, None, None, None, 0, C.byref(n))
+        if rc not in (PD_OK, PD_E_OVERFLOW):
+            self.check(rc)
+        cap = int(n.value)
+        kp = np.zeros((cap, 17, 3), np.float64)
+        sc = np.zeros((cap,), np.float64)
+        im = np.zeros((cap,), np.int32)
+        if cap:
+            self.check(self.L.pd_coco_rows(self._h, _ptr(kp), _ptr(sc), _ptr(im), cap, C.byref(n)))
+        return kp, sc, im
+
+    def image_resize_shape(self, h, w, scale, stride):
+        """``(resized_h, resized_w, pad_down, pad_right)`` of predict.py:56-57."""
+        v = [C.c_int32() for _ in range(4)]
+        rc = self.L.pd_image_resize_shape(h, w, float(scale), stride, *[C.byref(x) for x in v])
+        if rc != PD_OK:
+            raise ValueError('image_resize_shape: bad size %dx%d, scale %r or stride %d' % (h, w, scale, stride))
+        return tuple(x.value for x in v)
+
+    def image_resize_pad(self, img, scale, stride, pad_value, out_dtype=None):
+        """predict.py:56-57 on the device: cubic resize by ``scale``, then padding below / right
+        to a multiple of ``stride``.  ``img`` (h, w, C) uint8 or float32; returns
+        ``(padded (oh, ow, C), [0, 0, pad_down, pad_right])``."""
+        img = np.ascontiguousarray(img)
+        if img.ndim != 3 or img.dtype not in (np.uint8, np.float32):
+            raise ValueError('img must be (h, w, C) uint8 or float32, got %r %s' % (img.shape, img.dtype))
+        out_dtype = np.dtype(out_dtype or img.dtype)
+        h, w, ch = img.shape
+        rh, rw, pd, pr = self.image_resize_shape(h, w, scale, stride)
+        out = np.empty((rh + pd, rw + pr, ch), out_dtype)
+        code = {np.dtype(np.uint8): U8, np.dtype(np.float32): F32}
+        self.check(self.L.pd_image_resize_pad(self._h, _ptr(img), code[img.dtype], h, w, ch, float(scale), stride,
+                                              float(pad_value), _ptr(out), code[out_dtype], rh + pd, rw + pr, MEM_HOST))
+        return out, [0, 0, pd, pr]
+
+    def render(self, img, circles, ellipses, want_part=True, want_final=True):
+        """predict.py:256-307: ``circles`` (n, 3) int32 ``(x, y, colour)``, ``ellipses`` (m, 6) int32
+        ``(cx, cy, a, b, angle_degrees, colour)``; returns ``(part_image, final_image)`` uint8."""
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError('img must be (H, W, 3) uint8')
+        circles = np.ascontiguousarray(circles, np.int32).reshape(-1, 3)
+        ellipses = np.ascontiguousarray(ellipses, np.int32).reshape(-1, 6)
+        part = np.empty_like(img) if want_part else None
+        final = np.empty_like(img) if want_final else None
+        self.check(self.L.pd_render(self._h, _ptr(img), img.shape[0], img.shape[1], len(circles),
+                                    _ptr(circles) if len(circles) else None, len(ellipses),
+                                    _ptr(ellipses) if len(ellipses) else None, _ptr(part), _ptr(final)))
+        return part, final
+
     def debug_smoothed(self, B, H, W):
         out = np.empty((B, 18, H, W), np.float64)
         self.check(self.L.pd_debug_smoothed(self._h, _ptr(out)))
+        return out
+
+
+class Comm:
+    """A communicator of the library's own (RCCL loaded at run time, no framework needed):
+    ``Comm.unique_id()`` on one rank, the 128 bytes handed to the others, then
+    ``Comm(id, world, rank, device_id)`` on every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        L = lib()
+        rc = L.pd_comm_unique_id(buf)
+        if rc != PD_OK:
+            raise RuntimeError('pd_comm_unique_id failed (%d): %s' % (rc, L.pd_last_error(None).decode()))
+        return bytes(buf)
+
+    def __init__(self, unique_id, world, rank, device_id=0):
+        self._h = None
+        self.L = lib()
+        self.world, self.rank = world, rank
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        rc = self.L.pd_comm_create(buf, world, rank, device_id, C.byref(h))
+        if rc != PD_OK:
+            raise RuntimeError('pd_comm_create failed (%d): %s' % (rc, self.L.pd_last_error(None).decode()))
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            self.L.pd_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def gather(self, contexts, root=0, capacity=1 << 22):
+        """pd_gather: the skeleton buffers of every rank's contexts on ``root``.  Returns, on the
+        root, a list (rank-major, then context order) of uint8 arrays in the packed result
+        layout (``unpack_results`` reads them); None elsewhere."""
+        n = len(contexts)
+        arr = (C.c_void_p * n)(*[c._h for c in contexts])
+        is_root = self.rank == root
+        recv = np.zeros(capacity if is_root else 1, np.uint8)
+        sizes = (C.c_uint64 * (self.world * n))()
+        total = C.c_uint64()
+        rc = self.L.pd_gather(self._h, arr, n, root, _ptr(recv), capacity if is_root else 0, sizes, C.byref(total))
+        if rc != PD_OK:
+            msg = self.L.pd_comm_last_error(self._h).decode()
+            if rc == PD_E_OVERFLOW:
+                raise DecodeOverflow(msg)
+            raise RuntimeError('pd_gather failed (%d): %s' % (rc, msg))
+        if not is_root:
+            return None
+        out, off = [], 0
+        for v in sizes:
+            out.append(recv[off:off + int(v)])
+            off += (int(v) + 15) & ~15
         return out

@@ -38,3 +38,12 @@ def batch_records(results, image_ids):
     for b, image_id in enumerate(image_ids):
         out.extend(coco_records(results.candidate(b), results.subset(b), image_id))
     return out
+
+
+def device_records(ctx, image_ids):
+    """The same records for the batch a context has just decoded, with the keypoint rows
+    formed on the device (``pd_coco_rows``): nothing but the 17 x 3 rows, the scores and the
+    image index of every person crosses to the host."""
+    kp, score, image = ctx.coco_rows()
+    return [{"image_id": image_ids[int(image[i])], "category_id": 1, "keypoints": list(kp[i].reshape(-1)),
+             "score": score[i]} for i in range(len(score))]

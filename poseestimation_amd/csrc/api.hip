@@ -170,7 +170,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
-                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats, ctx->full_absmax};
+                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats, ctx->full_absmax, ctx->aux_dev, ctx->dbg_found};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (TableSlot& t : ctx->tabs) {
@@ -635,6 +635,29 @@ extern "C" int pd_parse(pd_ctx* ctx) {
     if (rc != PD_OK) return rc;
     ctx->have_persons = 1;
     ctx->packed = 0;
+    return PD_OK;
+}
+
+extern "C" int pd_debug_found(pd_ctx* ctx, int enable, int32_t* out) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    const size_t bytes = (size_t)ctx->cfg.max_batch * ctx->cfg.max_peaks_per_part * sizeof(int32_t);
+    if (out) {
+        if (!ctx->dbg_found) PD_FAIL(ctx, PD_E_STATE, "pd_debug_found: recording is off");
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PD_HIP(ctx, hipMemcpy(out, ctx->dbg_found, bytes, hipMemcpyDeviceToHost));
+    }
+    if (enable && !ctx->dbg_found) {
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->gen++;
+        PD_HIP(ctx, hipMalloc((void**)&ctx->dbg_found, bytes));
+        PD_HIP(ctx, hipMemset(ctx->dbg_found, 0, bytes));
+    } else if (!enable && ctx->dbg_found) {
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->gen++;
+        PD_HIP(ctx, hipFree(ctx->dbg_found));
+        ctx->dbg_found = nullptr;
+    }
     return PD_OK;
 }
 

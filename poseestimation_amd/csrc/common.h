@@ -212,6 +212,10 @@ struct pd_ctx {
     unsigned char* skel_dst;  // caller's device buffer for the skeleton copy of the results (or NULL)
     size_t skel_cap;
     int host_results;         // 0: with a skeleton buffer set, results go there only (no host mirror)
+    int32_t* dbg_found;       // [max_batch][PK] len(found) per limb-18 connection, when asked for (pd_debug_found)
+    // ---- scratch of the entry points either side of the decode (COCO rows, image resize, rendering) ----
+    unsigned char* aux_dev;
+    size_t aux_cap;
     // ---- stage timing (pd_profile) ----
     uint32_t prof_on;               // bit s set: stage s is timed
     int prof_open;                  // a start event is waiting for its stop
@@ -328,6 +332,9 @@ int pd_launch_hwc_to_planar(pd_ctx* ctx, const void* src, int dtype, int Csrc, i
 int pd_launch_planar_to_hwc(pd_ctx* ctx, const double* src, int C, int B, int H, int W, double* dst);
 int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W);
 void pd_host_cubic_table(int src_len, int dst_len, double scale, int32_t* ofs, float* coef);
+// Device tap tables of a resize (hs, ws) -> (Hd, Wd) in a slot of the context; sy / sx <= 0: the
+// ratio of the sizes, else the given source step per destination pixel (cv2.resize with fx, fy).
+int pd_upload_tables(pd_ctx* ctx, int hs, int ws, int Hd, int Wd, double sy, double sx, TableSlot* slot);
 void pd_up8_fill(Up8* u);
 int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
                            const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W,

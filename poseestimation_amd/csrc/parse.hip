@@ -19,6 +19,7 @@ struct ParseArgs {
     int32_t* person_count;
     int32_t* status;
     int only_flagged;  // != 0: only images the fast kernel handed over (count -1)
+    int32_t* dbg_found;  // [B][PK] or NULL: len(found) of every limb-18 connection (utils/postprocess.py:224-225)
 };
 
 // The table form for image b; tab holds max_persons rows of 20 doubles in LDS.
@@ -38,11 +39,12 @@ __device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
             const double ida = (double)r.id_a, idb = (double)r.id_b;
             const double conf_a = conf[2 * ci], conf_b = conf[2 * ci + 1];
             // find(): rows with person[a] == id_a or person[b] == id_b, in row order
-            int found = 0, j0 = -1, j1 = -1;
+            int found = 0, j0 = -1, j1 = -1, hits = 0;
             for (int base = 0; base < n; base += 64) {
                 const int j = base + lane;
                 const bool hit = j < n && (tab[j * 20 + pa] == ida || tab[j * 20 + pb] == idb);
                 unsigned long long m = __ballot(hit);
+                hits += __builtin_popcountll(m);
                 while (m != 0ull && found < 3) {
                     const int f = base + __builtin_ctzll(m);
                     if (found == 0) j0 = f;
@@ -51,6 +53,7 @@ __device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
                     m &= m - 1ull;
                 }
             }
+            if (a.dbg_found && k == 18 && lane == 0) a.dbg_found[(size_t)b * a.PK + ci] = hits;
             if (found == 0) {
                 if (a.mode == PD_MODE_D || k < 17) {  // utils/postprocess.py:196 / predict.py:228
                     if (n >= a.max_persons) {
@@ -599,7 +602,8 @@ int pd_launch_parse(pd_ctx* ctx) {
     a.status = ctx->status;
     const size_t lds = (size_t)a.max_persons * 20 * sizeof(double);
     pd_prof_begin(ctx, PD_STAGE_PARSE);
-    if (ctx->impl == PD_IMPL_SIMPLE) {
+    a.dbg_found = ctx->dbg_found;
+    if (ctx->impl == PD_IMPL_SIMPLE || ctx->dbg_found) {
         a.only_flagged = 0;
         hipLaunchKernelGGL(k_parse, dim3(ctx->B), dim3(64), lds, ctx->stream, a);
     } else {

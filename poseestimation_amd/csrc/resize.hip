@@ -48,8 +48,7 @@ void pd_up8_fill(Up8* u) {
 }
 
 // Device tables: ints [y ofs | x ofs], floats [y coef | x coef].
-static int upload_tables(pd_ctx* ctx, int hs, int ws, int Hd, int Wd, double sy, double sx,
-                         TableSlot* slot) {
+int pd_upload_tables(pd_ctx* ctx, int hs, int ws, int Hd, int Wd, double sy, double sx, TableSlot* slot) {
     int32_t** d_i = &slot->i;
     float** d_f = &slot->f;
     size_t* cap = &slot->cap;
@@ -95,7 +94,7 @@ static int upload_tables(pd_ctx* ctx, int hs, int ws, int Hd, int Wd, double sy,
 int pd_build_tables(pd_ctx* ctx, int h, int w, int H, int W) {
     if (ctx->tab_h == h && ctx->tab_w == w && ctx->tab_H == H && ctx->tab_W == W && ctx->tabs[0].i) return PD_OK;
     // cv2.resize(.., (0,0), fx=8, fy=8): scale = 1/8; rows/cols beyond the crop are never read
-    int rc = upload_tables(ctx, h, w, H, W, 0.125, 0.125, &ctx->tabs[0]);
+    int rc = pd_upload_tables(ctx, h, w, H, W, 0.125, 0.125, &ctx->tabs[0]);
     if (rc != PD_OK) return rc;
     ctx->tab_h = h;
     ctx->tab_w = w;
@@ -439,7 +438,7 @@ int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, 
         sc.crop_w = crop_w[m];
         sc.identity = crop_h[m] == H && crop_w[m] == W;
         if (!sc.identity) {
-            int rc = upload_tables(ctx, crop_h[m], crop_w[m], H, W, -1.0, -1.0, &ctx->tabs[2 + m]);
+            int rc = pd_upload_tables(ctx, crop_h[m], crop_w[m], H, W, -1.0, -1.0, &ctx->tabs[2 + m]);
             if (rc != PD_OK) return rc;
             sc.ty = ctx->tabs[2 + m].ty;
             sc.tx = ctx->tabs[2 + m].tx;

@@ -7,7 +7,7 @@ return structures), computed by the HIP kernels of libposedecode.so.
 
 Known deviations, all deliberate:
 * the stray ``print(connection, len(found))`` for limb 18 (utils/postprocess.py:224-225)
-  is not reproduced;
+  is produced only when the module attribute ``debug_print`` is set to True;
 * peak ids inside one part must be unique (they are when they come from get_peaks);
 * a sample index outside the PAF array is clamped instead of raising / wrapping;
 * at most 400 persons can be open at once while one image is parsed.
@@ -19,6 +19,7 @@ from . import _ffi
 from .config import limb_seq, LIMB_FROM, LIMB_TO  # noqa: F401  (limb_seq is part of the reference module's surface)
 
 _MODE = _ffi.MODE_P
+debug_print = False   # True: multi_person_parse prints the reference's limb-18 debug lines
 _state = {'ctx': None, 'key': None}
 
 
@@ -205,7 +206,14 @@ def multi_person_parse(peaks, all_connections, special_limb_idx):
     ctx = _context(1, 1, pk, 1, persons_cap)
     ctx.set_mode(_MODE)
     _upload_connections(ctx, peaks, all_connections, special_limb_idx)
+    want_print = debug_print and 18 not in special_limb_idx and len(all_connections[18]) > 0
+    if want_print:
+        ctx.debug_found(True)
     ctx.parse()
     ctx.pack()
     res = ctx.fetch()
+    if want_print:
+        found = ctx.debug_found(False, read=True)[0]
+        for i, connection in enumerate(all_connections[18]):     # utils/postprocess.py:224-225
+            print(connection, int(found[i]))
     return res['persons'].copy()

@@ -4,8 +4,9 @@
 * ``upsample_average``       predict.py:51-72   (x8 bicubic, un-pad, resize, multi-scale average)
 * ``decode``                 predict.py:82-254  -> ``(candidate, all_peaks, subset)``
 * ``DecodeEngine``           the batched form: many images per call, results packed
-* ``detect``                 predict.py:45 signature, for callers that bring their own
-                             image resize (cv2 is not a dependency of this package)
+* ``resize_pad``             predict.py:56-57  (image-side cubic resize + padding, on the device)
+* ``detect``                 predict.py:45 signature; the network is the caller's ``predict_func``
+* ``visualize``              predict.py:256-307 (peak discs and limb ellipses, rasterised on the device)
 
 ``mode='D'`` follows predict.py (peak tuples ``(x, y, score, id)``, PAF channel 2k with
 dx, sample index rounded half-even, connection rows ``[id_a, id_b, score, i, j]``);
@@ -175,27 +176,82 @@ def decode(heatmap_avg, paf_avg, thre1=THRE1, thre2=THRE2, mode='D'):
     return cand, peaks, subset
 
 
+def _resize_context(h, w):
+    # a context of the cached kind: the image-side entry points only use its stream and scratch
+    return _pp._context(max(h, 1), max(w, 1), 16, 16, 16)
+
+
+def resize_pad(img, scale, stride=STRIDE, pad_value=PAD_VALUE):
+    """predict.py:56-57 on the device: ``cv2.resize(img, (0, 0), fx=scale, fy=scale, INTER_CUBIC)``
+    then ``pad_right_down_corner``.  Returns ``(img_padded, pad)``; a uint8 image stays uint8
+    (float32 evaluation, rounded half to even and saturated)."""
+    img = np.asarray(img)
+    if img.dtype not in (np.uint8, np.float32):
+        img = img.astype(np.float32)
+    ctx = _resize_context(img.shape[0], img.shape[1])
+    return ctx.image_resize_pad(img, scale, stride, pad_value)
+
+
 def detect(img, predict_func, draw_result=False, resize=None):
     """predict.py:45 ``detect(img, predict_func, draw_result=False)`` ->
-    ``(candidate, all_peaks, subset)``.  The multi-scale loop is predict.py:49-72; the
-    image-side ``cv2.resize`` (predict.py:56) must be supplied as ``resize(img, scale)``
-    because this package does not depend on OpenCV (cv2 is used if importable)."""
-    if resize is None:
-        try:
-            import cv2
-        except ImportError:
-            raise RuntimeError('detect() needs an image resize: pass resize=callable(img, scale) '
-                               'or install cv2')
-
-        def resize(im, s):
-            return cv2.resize(im, (0, 0), fx=s, fy=s, interpolation=cv2.INTER_CUBIC)
+    ``(candidate, all_peaks, subset)``.  The multi-scale loop is predict.py:49-72: the
+    image-side cubic resize and padding (predict.py:56-57) run on the device
+    (``resize_pad``) unless ``resize(img, scale)`` is given, in which case its result is
+    padded on the host; the network call is the caller's ``predict_func``."""
     h, w = img.shape[:2]
     outs, pads = [], []
     for x in SCALE_SEARCH:
         scale = x * IMG_Y / h                                   # predict.py:49
-        padded, pad = pad_right_down_corner(resize(img, scale), STRIDE, PAD_VALUE)
+        if resize is None:
+            padded, pad = resize_pad(img, scale, STRIDE, PAD_VALUE)
+        else:
+            padded, pad = pad_right_down_corner(resize(img, scale), STRIDE, PAD_VALUE)
         heatmap, paf = predict_func(np.expand_dims(padded, axis=0))   # predict.py:59-61
         outs.append((heatmap, paf))
         pads.append(pad)
     heat_avg, paf_avg = upsample_average(outs, pads, (h, w))
     return decode(heat_avg, paf_avg, THRE1, THRE2, mode='D')
+
+
+def render_lists(candidate, all_peaks, subset):
+    """The draw lists of predict.py:265-299: ``circles (n, 3)`` = (x, y, colour) for every peak
+    in part order, ``ellipses (m, 6)`` = (cx, cy, a, b, angle, colour), the arguments of
+    ``cv2.ellipse2Poly`` at predict.py:297, for every limb (except 9 and 13) and person."""
+    import math
+    circles = [(int(p[0]), int(p[1]), i) for i in range(18) for p in all_peaks[i]]
+    ellipses = []
+    candidate = np.asarray(candidate, np.float64).reshape(-1, 4)
+    for i in range(19):
+        if i == 9 or i == 13:                                    # predict.py:285
+            continue
+        for n in range(len(subset)):
+            index = np.asarray(subset[n])[np.array(_pp.limb_seq[i])]
+            if -1 in index:
+                continue
+            Y = candidate[index.astype(int), 0]                  # predict.py:290-291 (the names are the
+            X = candidate[index.astype(int), 1]                  # reference's: column 0 is x in mode D)
+            mX, mY = np.mean(X), np.mean(Y)
+            length = ((X[0] - X[1]) ** 2 + (Y[0] - Y[1]) ** 2) ** 0.5
+            angle = math.degrees(math.atan2(X[0] - X[1], Y[0] - Y[1]))
+            ellipses.append((int(mY), int(mX), int(length / 2), 4, int(angle), i % 18))
+    return (np.array(circles, np.int32).reshape(-1, 3), np.array(ellipses, np.int32).reshape(-1, 6))
+
+
+def visualize(img, candidate, all_peaks, subset, write=True):
+    """predict.py:256-307 ``visualize(img, candidate, all_peaks, subset)``: the peak discs
+    blended over the image (part.jpg) and the limb ellipses blended into the canvas
+    (final.jpg), rasterised on the device.  Returns ``(part_image, final_image)``; with
+    ``write`` and cv2 importable the two files are written as the reference does."""
+    img = np.ascontiguousarray(img, np.uint8)
+    circles, ellipses = render_lists(candidate, all_peaks, subset)
+    ctx = _resize_context(img.shape[0], img.shape[1])
+    part, final = ctx.render(img, circles, ellipses)
+    if write:
+        try:
+            import cv2
+        except ImportError:
+            cv2 = None
+        if cv2 is not None:
+            cv2.imwrite('part.jpg', part)
+            cv2.imwrite('final.jpg', final)
+    return part, final

@@ -234,3 +234,54 @@ def test_coco_records_match_oracle_restatement():
         assert g['image_id'] == 42 and g['category_id'] == 1 and g['score'] == w['score']
         assert [float(v) for v in g['keypoints']] == [float(v) for v in w['keypoints']]
     assert coco.coco_records(np.zeros((0, 4)), np.zeros((0, 20)), 1) == []
+
+
+def test_image_resize_shape_through_the_c_abi():
+    """pd_image_resize_shape is host arithmetic (no device work): cv2.resize's destination size
+    for fx = fy = scale is the product rounded half to even, the pad is predict.py:23-24."""
+    import ctypes as C
+    from poseestimation_amd import _ffi
+    L = _ffi.lib()
+    for h, w, scale, stride in [(97, 131, 0.5 * 368 / 97, 8), (480, 640, 368 / 480.0, 8), (5, 5, 0.5, 8), (64, 48, 1.0, 8),
+                                (33, 35, 4.1, 4)]:
+        v = [C.c_int32() for _ in range(4)]
+        assert L.pd_image_resize_shape(h, w, scale, stride, *[C.byref(x) for x in v]) == 0
+        rh, rw = int(round(h * scale)), int(round(w * scale))
+        assert [x.value for x in v] == [rh, rw, (stride - rh % stride) % stride, (stride - rw % stride) % stride]
+    assert L.pd_image_resize_shape(0, 5, 1.0, 8, None, None, None, None) == _ffi.PD_E_INVALID
+    assert L.pd_image_resize_shape(5, 5, 0.0, 8, None, None, None, None) == _ffi.PD_E_INVALID
+
+
+def test_oracle_image_resize_pad_properties():
+    from oracle import decode_ref as ref
+    rng = np.random.RandomState(4)
+    img = rng.randint(0, 256, size=(40, 52, 3)).astype(np.uint8)
+    same, pad = ref.image_resize_pad(img, 1.0, 8, 128)
+    assert pad == [0, 0, 0, 4] and same.dtype == np.uint8
+    assert np.array_equal(same[:, :52], img) and np.all(same[:, 52:] == 128)
+    flat = np.full((30, 30, 3), 77, np.uint8)
+    up, pad = ref.image_resize_pad(flat, 2.3, 8, 128)
+    assert up.shape == (72, 72, 3) and pad == [0, 0, 3, 3]
+    assert np.all(up[:69, :69] == 77)        # the cubic weights sum to one (up to float32 rounding, gone after rint)
+
+
+def test_render_lists_follow_visualize():
+    """predict.py:265-299: one disc per peak in part order; one ellipse per limb (not 9, 13) and
+    person that has both joints, with ellipse2Poly's integer arguments."""
+    from poseestimation_amd.predict_decode import render_lists
+    peaks = [[] for _ in range(18)]
+    peaks[1] = [(10, 20, 0.9, 0)]        # mode D tuples: (x, y, score, id)
+    peaks[8] = [(40, 60, 0.8, 1)]
+    peaks[2] = [(13, 20, 0.8, 2)]
+    peaks[16] = [(17, 5, 0.8, 3)]
+    cand = np.array([[10, 20, 0.9, 0], [40, 60, 0.8, 1], [13, 20, 0.8, 2], [17, 5, 0.8, 3]], float)
+    person = -np.ones(20)
+    person[[1, 8, 2, 16]] = [0, 1, 2, 3]
+    circles, ellipses = render_lists(cand, peaks, person[None])
+    assert circles.tolist() == [[10, 20, 1], [13, 20, 2], [40, 60, 8], [17, 5, 16]]
+    # limb 0 = parts 1 -> 8: centre (25, 40), half length int(50 / 2), angle of (dy, dx) = (-40, -30) from b to a
+    # limb 6 = parts 1 -> 2: centre (int(11.5), 20), half length int(1.5) = 1, angle atan2(0, -3) = 180
+    # limb 9 = parts 2 -> 16 is skipped
+    import math
+    assert ellipses.tolist() == [[25, 40, 25, 4, int(math.degrees(math.atan2(-40, -30))), 0],
+                                 [11, 20, 1, 4, 180, 6]]
