@@ -393,6 +393,245 @@ k_resize_fused(AvgArgs a) {
         if (c < nch) out[c * n] = acc[c];
 }
 
+// ---- the same pass with the index work hoisted out of a loop over channel groups ------------
+// Which source pixels, horizontal sums and patch positions a thread touches depends on the
+// tile and the scale only, not on the channels: a workgroup owns one output tile of one image
+// and walks the channel groups, with every LDS byte offset and global element offset of its
+// threads worked out once and kept in registers (16-bit fields, two per register).  The
+// arithmetic of a group is that of k_resize_fused, stage by stage.
+#define RT_MAXS 4        // scales per call this kernel is built for (more: k_resize_fused)
+#define RT_AQ 3          // horizontal sums per thread and scale: FT_HSUM <= 3 * 256
+
+struct TileScale {       // per scale, uniform over the workgroup
+    int r_lo, c_lo, ph, pw, j_lo, nj, i_lo, ni;
+};
+struct ThreadScale {     // per scale, per thread
+    unsigned o0;         // stage 0: element offset of this thread's source pixel (group 0), ~0u = none
+    // stage A: byte offsets (< 4096) of the four source pixels in srcp, two per word; bits 12-15 of
+    // a01: phase of the column, 8 = no element
+    unsigned a01[RT_AQ], a23[RT_AQ];
+    unsigned b;          // stage B: column | first row << 8 | end row << 20
+    // stage C: byte offset of the first tap column within a patch row (bits 0-11) and of the first
+    // tap row in the patch (bits 0-14); the three bits above say whether the next tap moves on by
+    // one column / one row (clamped taps repeat)
+    unsigned cx, cr;
+};
+
+__device__ __forceinline__ float4 lds4(const float4* base, unsigned byte_off) {
+    return *(const float4*)((const char*)base + byte_off);
+}
+
+template <bool POW2, int NS>
+__global__ void __launch_bounds__(256, 4)
+k_resize_tiles(AvgArgs a, int groups_per_block) {
+    __shared__ float4 patch[FT_PATCH];
+    __shared__ float4 hsum[FT_HSUM];
+    __shared__ float4 srcp[FT_SRC];
+    __shared__ float4 s_up[8];
+    const int tid = threadIdx.x;
+    if (tid < 8) s_up[tid] = make_float4(a.up8.c[tid][0], a.up8.c[tid][1], a.up8.c[tid][2], a.up8.c[tid][3]);
+    const size_t n = (size_t)a.H * a.W;
+    const int tiles_x = (a.W + FT_TW - 1) / FT_TW, tiles = tiles_x * ((a.H + FT_TH - 1) / FT_TH);
+    const int per_xcd = (tiles + 7) / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;   // tiles that share source rows share an XCD
+    if (tile >= tiles) return;
+    const int X0 = (tile % tiles_x) * FT_TW, Y0 = (tile / tiles_x) * FT_TH;
+    const bool inside = X0 + (tid % FT_TW) < a.W && Y0 + (tid / FT_TW) < a.H;
+    const int X = min(X0 + (tid % FT_TW), a.W - 1), Y = min(Y0 + (tid / FT_TW), a.H - 1);
+    const int Ylast = min(Y0 + FT_TH - 1, a.H - 1), Xlast = min(X0 + FT_TW - 1, a.W - 1);
+    const int b = blockIdx.z;
+    const int n_groups = (a.C + FT_CH - 1) / FT_CH;
+    const int g_begin = blockIdx.y * groups_per_block, g_end = min(n_groups, g_begin + groups_per_block);
+
+    TileScale ts[NS];
+    ThreadScale th[NS];
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+        const ScaleSrc& sc = a.s[m];
+        TileScale& t = ts[m];
+        ThreadScale& q = th[m];
+        if (sc.identity) {
+            t.r_lo = Y0;
+            t.c_lo = X0;
+            t.ph = Ylast - Y0 + 1;
+            t.pw = Xlast - X0 + 1;
+        } else {
+            t.r_lo = pd_clampi(sc.ty.ofs[Y0], 0, sc.crop_h - 1);
+            t.c_lo = pd_clampi(sc.tx.ofs[X0], 0, sc.crop_w - 1);
+            t.ph = pd_clampi(sc.ty.ofs[Ylast] + 3, 0, sc.crop_h - 1) - t.r_lo + 1;
+            t.pw = pd_clampi(sc.tx.ofs[Xlast] + 3, 0, sc.crop_w - 1) - t.c_lo + 1;
+        }
+        // uniform over the workgroup: keep them in scalar registers
+        t.r_lo = __builtin_amdgcn_readfirstlane(t.r_lo);
+        t.c_lo = __builtin_amdgcn_readfirstlane(t.c_lo);
+        t.ph = __builtin_amdgcn_readfirstlane(t.ph);
+        t.pw = __builtin_amdgcn_readfirstlane(t.pw);
+        t.j_lo = pd_up8_ofs(t.r_lo);
+        t.nj = pd_up8_ofs(t.r_lo + t.ph - 1) + 3 - t.j_lo + 1;
+        t.i_lo = pd_clampi(pd_up8_ofs(t.c_lo), 0, sc.ws - 1);
+        t.ni = pd_clampi(pd_up8_ofs(t.c_lo + t.pw - 1) + 3, 0, sc.ws - 1) - t.i_lo + 1;
+        // stage 0: one source pixel per thread (nj * ni <= FT_SRC <= 256)
+        q.o0 = ~0u;
+        if (tid < t.nj * t.ni) {
+            const int jj = tid / t.ni, ii = tid - jj * t.ni;
+            q.o0 = (unsigned)((pd_clampi(t.j_lo + jj, 0, sc.hs - 1) * sc.ws + t.i_lo + ii) * a.C);
+        }
+        // stage A: horizontal sum e = source row jj, patch column c
+#pragma unroll
+        for (int k = 0; k < RT_AQ; ++k) {
+            const int e = tid + 256 * k;
+            unsigned ph = 8, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+            if (e < t.nj * t.pw) {
+                const int jj = e / t.pw, c = e - jj * t.pw;
+                const int col = t.c_lo + c, x0 = pd_up8_ofs(col), hi = sc.ws - 1;
+                const int rowb = jj * t.ni - t.i_lo;
+                ph = (unsigned)pd_up8_phase(col);
+                i0 = (unsigned)(rowb + pd_clampi(x0, 0, hi)) * 16u;
+                i1 = (unsigned)(rowb + pd_clampi(x0 + 1, 0, hi)) * 16u;
+                i2 = (unsigned)(rowb + pd_clampi(x0 + 2, 0, hi)) * 16u;
+                i3 = (unsigned)(rowb + pd_clampi(x0 + 3, 0, hi)) * 16u;
+            }
+            q.a01[k] = i0 | (ph << 12) | (i1 << 16);
+            q.a23[k] = i2 | (i3 << 16);
+        }
+        // stage B: a run of rows of one patch column
+        {
+            const int G = max(1, 256 / t.pw), rpg = (t.ph + G - 1) / G;
+            q.b = 0;
+            if (tid < G * t.pw) {
+                const int g = tid / t.pw, c = tid - g * t.pw;
+                const int r0 = min(t.ph, g * rpg), r1 = min(t.ph, (g + 1) * rpg);
+                q.b = (unsigned)c | ((unsigned)r0 << 8) | ((unsigned)r1 << 20);
+            }
+        }
+        // stage C: the taps of this thread's output pixel
+        if (sc.identity) {
+            q.cx = 0;
+            q.cr = (unsigned)((Y - t.r_lo) * t.pw + (X - t.c_lo)) * 16u;
+        } else {
+            const int x0 = sc.tx.ofs[X], y0 = sc.ty.ofs[Y];
+            int xo[4], ro[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xo[k] = pd_clampi(x0 + k, 0, sc.crop_w - 1) - t.c_lo;
+                ro[k] = pd_clampi(y0 + k, 0, sc.crop_h - 1) - t.r_lo;
+            }
+            q.cx = (unsigned)xo[0] * 16u | (unsigned)(xo[1] - xo[0]) << 12 | (unsigned)(xo[2] - xo[1]) << 13 |
+                   (unsigned)(xo[3] - xo[2]) << 14;
+            q.cr = (unsigned)(ro[0] * t.pw) * 16u | (unsigned)(ro[1] - ro[0]) << 15 | (unsigned)(ro[2] - ro[1]) << 16 |
+                   (unsigned)(ro[3] - ro[2]) << 17;
+        }
+    }
+    __syncthreads();
+
+    float amax = 0.f;
+    for (int g = g_begin; g < g_end; ++g) {
+        const int ch0 = g * FT_CH;
+        const int nch = min(FT_CH, a.C - ch0);
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        // The packed fields are re-read as opaque values in every round: otherwise the compiler
+        // unpacks them (and loads the tap weights) ahead of the loop and the unpacked copies of
+        // all scales no longer fit the registers of four workgroups per CU.
+        int Xo = X, Yo = Y;
+        asm volatile("" : "+v"(Xo), "+v"(Yo));
+#pragma unroll
+        for (int m = 0; m < NS; ++m) {
+            ThreadScale& w = th[m];
+            asm volatile("" : "+v"(w.o0), "+v"(w.b), "+v"(w.cx), "+v"(w.cr));
+#pragma unroll
+            for (int k = 0; k < RT_AQ; ++k) asm volatile("" : "+v"(w.a01[k]), "+v"(w.a23[k]));
+        }
+#pragma unroll
+        for (int m = 0; m < NS; ++m) {
+            const ScaleSrc& sc = a.s[m];
+            const TileScale& t = ts[m];
+            const ThreadScale& q = th[m];
+            // 0: the source pixels the patch draws on
+            if (q.o0 != ~0u) srcp[tid] = load_channels(sc.lo + (size_t)b * sc.hs * sc.ws * a.C + ch0 + q.o0, nch);
+            __syncthreads();
+            // A: horizontal sums
+#pragma unroll
+            for (int k = 0; k < RT_AQ; ++k) {
+                const unsigned ph = (q.a01[k] >> 12) & 15u;
+                if (ph < 8u)
+                    hsum[tid + 256 * k] = tap4v(lds4(srcp, q.a01[k] & 0xfffu), lds4(srcp, q.a01[k] >> 16),
+                                                lds4(srcp, q.a23[k] & 0xffffu), lds4(srcp, q.a23[k] >> 16), s_up[ph]);
+            }
+            __syncthreads();
+            // B: the patch of the x8 map, a run of rows per thread
+            {
+                const int c = (int)(q.b & 255u), r0 = (int)((q.b >> 8) & 4095u), r1 = (int)(q.b >> 20);
+                int cur = -0x40000000;
+                float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0, h2 = h0, h3 = h0;
+                for (int r = r0; r < r1; ++r) {
+                    const int rabs = t.r_lo + r;
+                    const int y0 = pd_up8_ofs(rabs) - t.j_lo;
+                    if (y0 != cur) {
+                        const float4* col = hsum + y0 * t.pw + c;
+                        if (y0 == cur + 1) {
+                            h0 = h1;
+                            h1 = h2;
+                            h2 = h3;
+                        } else {
+                            h0 = col[0];
+                            h1 = col[t.pw];
+                            h2 = col[2 * t.pw];
+                        }
+                        h3 = col[3 * t.pw];
+                        cur = y0;
+                    }
+                    patch[r * t.pw + c] = tap4v(h0, h1, h2, h3, s_up[pd_up8_phase(rabs)]);
+                }
+            }
+            __syncthreads();
+            // C: the second resize from the patch
+            float4 v;
+            if (sc.identity) {
+                v = lds4(patch, q.cr);
+            } else {
+                const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)Xo);
+                const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Yo);
+                const unsigned x0 = q.cx & 0xfffu, x1 = x0 + ((q.cx >> 8) & 16u), x2 = x1 + ((q.cx >> 9) & 16u),
+                               x3 = x2 + ((q.cx >> 10) & 16u);
+                const unsigned rowb = (unsigned)t.pw * 16u;
+                const unsigned r0 = q.cr & 0x7fffu, r1 = r0 + ((q.cr >> 15) & 1u) * rowb, r2 = r1 + ((q.cr >> 16) & 1u) * rowb,
+                               r3 = r2 + ((q.cr >> 17) & 1u) * rowb;
+                // two tap rows at a time: all sixteen taps in flight at once would cost 64 registers
+                const float4 v0 = tap4v(lds4(patch, r0 + x0), lds4(patch, r0 + x1), lds4(patch, r0 + x2), lds4(patch, r0 + x3), ac);
+                const float4 v1 = tap4v(lds4(patch, r1 + x0), lds4(patch, r1 + x1), lds4(patch, r1 + x2), lds4(patch, r1 + x3), ac);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 v2 = tap4v(lds4(patch, r2 + x0), lds4(patch, r2 + x1), lds4(patch, r2 + x2), lds4(patch, r2 + x3), ac);
+                const float4 v3 = tap4v(lds4(patch, r3 + x0), lds4(patch, r3 + x1), lds4(patch, r3 + x2), lds4(patch, r3 + x3), ac);
+                v = tap4v(v0, v1, v2, v3, bc);
+            }
+            acc0 = acc0 + (double)avg_share<POW2>(v.x, a);
+            acc1 = acc1 + (double)avg_share<POW2>(v.y, a);
+            acc2 = acc2 + (double)avg_share<POW2>(v.z, a);
+            acc3 = acc3 + (double)avg_share<POW2>(v.w, a);
+            // no barrier: the next stage 0 writes srcp (last read before two barriers), the next
+            // stage A writes hsum behind a barrier, the next stage B the patch behind two
+        }
+        if (inside) {
+            double* out = a.dst + ((size_t)b * a.C + ch0) * n + (size_t)Y * a.W + X;
+            out[0] = acc0;
+            amax = fmaxf(amax, (float)fabs(acc0));
+            if (nch > 1) {
+                out[n] = acc1;
+                amax = fmaxf(amax, (float)fabs(acc1));
+            }
+            if (nch > 2) {
+                out[2 * n] = acc2;
+                amax = fmaxf(amax, (float)fabs(acc2));
+            }
+            if (nch > 3) {
+                out[3 * n] = acc3;
+                amax = fmaxf(amax, (float)fabs(acc3));
+            }
+        }
+    }
+    if (a.absmax) pd_wave_absmax(amax, a.absmax + b);
+}
+
 // Whether every tile's patch of the second resize (crop -> H x W) fits the staging areas of
 // k_resize_fused; the same extents the kernel derives from the device tables.
 static bool patches_fit(int crop_h, int crop_w, int H, int W) {
@@ -417,7 +656,19 @@ static bool patches_fit(int crop_h, int crop_w, int H, int W) {
         max_pw = std::max(max_pw, pw);
         max_ni = std::max(max_ni, pd_up8_ofs(c_lo + pw - 1) + 3 - pd_up8_ofs(c_lo) + 1);
     }
-    return max_ph * max_pw <= FT_PATCH && max_nj * max_pw <= FT_HSUM && max_nj * max_ni <= FT_SRC;
+    // (the tile kernel also packs a patch column in 8 bits and a patch row in 12)
+    return max_ph * max_pw <= FT_PATCH && max_nj * max_pw <= FT_HSUM && max_nj * max_ni <= FT_SRC && max_pw <= 255 &&
+           max_ph <= 4095;
+}
+
+template <bool POW2>
+static void launch_tiles(int ns, dim3 grid, hipStream_t stream, const AvgArgs& a, int gpb) {
+    switch (ns) {
+        case 1: hipLaunchKernelGGL((k_resize_tiles<POW2, 1>), grid, dim3(256), 0, stream, a, gpb); break;
+        case 2: hipLaunchKernelGGL((k_resize_tiles<POW2, 2>), grid, dim3(256), 0, stream, a, gpb); break;
+        case 3: hipLaunchKernelGGL((k_resize_tiles<POW2, 3>), grid, dim3(256), 0, stream, a, gpb); break;
+        default: hipLaunchKernelGGL((k_resize_tiles<POW2, 4>), grid, dim3(256), 0, stream, a, gpb); break;
+    }
 }
 
 // All scales of one map family (C = 19 or 38): srcs[m] is (B, hs[m], ws[m], C) on the device.
@@ -456,7 +707,20 @@ int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, 
     const dim3 grid((tiles + 7) / 8 * 8, (C + FT_CH - 1) / FT_CH, B);
     const bool pow2 = (n_scales & (n_scales - 1)) == 0;
     if (pow2) a.n_rcp = 1.0f / (float)n_scales;
-    if (pow2 && !direct)
+    // the tile kernel packs LDS offsets in 16 bits and patch columns in 8: every staged patch fits that
+    static const bool old_kernel = getenv("PD_RESIZE_PER_GROUP") != nullptr;  // comparison runs
+    if (!direct && n_scales <= RT_MAXS && !old_kernel) {
+        const int n_groups = (C + FT_CH - 1) / FT_CH;
+        // enough workgroups to fill the chip several times over, as few channel chunks as that allows
+        int chunks = (int)((4096 + (size_t)tiles * B - 1) / ((size_t)tiles * B));
+        chunks = chunks < 1 ? 1 : (chunks > n_groups ? n_groups : chunks);
+        const int gpb = (n_groups + chunks - 1) / chunks;
+        const dim3 tgrid((tiles + 7) / 8 * 8, (n_groups + gpb - 1) / gpb, B);
+        if (pow2)
+            launch_tiles<true>(n_scales, tgrid, ctx->stream, a, gpb);
+        else
+            launch_tiles<false>(n_scales, tgrid, ctx->stream, a, gpb);
+    } else if (pow2 && !direct)
         hipLaunchKernelGGL((k_resize_fused<true, false>), grid, dim3(256), 0, ctx->stream, a);
     else if (pow2)
         hipLaunchKernelGGL((k_resize_fused<true, true>), grid, dim3(256), 0, ctx->stream, a);
