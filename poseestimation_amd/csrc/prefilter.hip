@@ -1049,8 +1049,9 @@ k_full_filter(FullFilterArgs a) {
         s_slack[0] = t;
         s_slack[1] = e;
     }
-    for (int i = tid; i < 2 * (FF_COLS + 4); i += FF_NT) sbuf[i] = 0.f;
-    for (int i = tid; i < 2 * (FF_COLS + 2 * PD_GR + 2); i += FF_NT) ybuf[i] = 0.f;
+    // (the workgroup has as many wavefronts as the strip has column pairs, not always FF_NT threads)
+    for (int i = tid; i < 2 * (FF_COLS + 4); i += blockDim.x) sbuf[i] = 0.f;
+    for (int i = tid; i < 2 * (FF_COLS + 2 * PD_GR + 2); i += blockDim.x) ybuf[i] = 0.f;
     __syncthreads();
     const float thr_lo = s_slack[0], e2 = s_slack[1];
     const double* col = a.full + ((size_t)b * a.Cfull + part) * (size_t)H * W + (act0 ? c : 0);
@@ -1115,7 +1116,10 @@ int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr) {
     f.cand_count = ctx->cand_count;
     f.cand_n = counters;
     pd_prof_begin(ctx, PD_STAGE_FILTER);
-    hipLaunchKernelGGL(k_full_filter, dim3(f.n_strips, PD_N_PARTS, B), dim3(FF_NT), 0, ctx->stream, f);
+    // threads: one per column pair of the widest strip (owned columns + 13 either side, even start)
+    int nt = ((min(W, f.strip_w + halo) + 1) / 2 + 63) / 64 * 64;
+    if (nt > FF_NT) nt = FF_NT;
+    hipLaunchKernelGGL(k_full_filter, dim3(f.n_strips, PD_N_PARTS, B), dim3(nt), 0, ctx->stream, f);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
 
