@@ -104,6 +104,7 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     CRH(hipMemset(ctx->zero_block, 0, ctx->zero_bytes));
     ctx->zero_clean = 1;
     CR(dev_alloc(ctx, (void**)&ctx->full_absmax, B * sizeof(float)));
+    CR(dev_alloc(ctx, (void**)&ctx->plane_slack, B * PD_N_PARTS * sizeof(float2)));
     CR(dev_alloc(ctx, (void**)&ctx->fstats, 4 * sizeof(int64_t)));
     CRH(hipMemset(ctx->fstats, 0, 4 * sizeof(int64_t)));
     ctx->raw_count = ctx->zero_block;
@@ -170,7 +171,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
-                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats, ctx->full_absmax, ctx->aux_dev, ctx->dbg_found};
+                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats, ctx->full_absmax, ctx->aux_dev, ctx->dbg_found, ctx->plane_slack};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (TableSlot& t : ctx->tabs) {

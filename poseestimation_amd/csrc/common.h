@@ -174,6 +174,7 @@ struct pd_ctx {
     float* full_absmax;              // [max_batch] max |value| of the full-resolution heatmaps per image (rounded up)
     int full_absmax_ok;              // full_absmax bounds the maps in full_heat
     float* absmax;                   // [B] max |heat| per image
+    float2* plane_slack;             // [max_batch * 18] (thr_lo, e2) of the candidate test, per plane
     float* heat_planar;              // (B, 19, h, w) copy of the network heatmaps
     size_t heat_planar_cap;
     float* paf_pairs;                // (B, 19, h, w, 2) copy of the PAFs, made for large batches only

@@ -230,7 +230,7 @@ k_heat_planar(const float* __restrict__ lo, int npix, float* __restrict__ planar
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     if ((tid & 63) == 0) s_red[tid >> 6] = m;
     __syncthreads();
-    if (tid == 0)
+    if (tid == 0 && absmax_bits)
         atomicMax(absmax_bits + b, __float_as_uint(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]))));
     float* dst = planar + (size_t)b * PD_CH_HEAT * npix + p0;
     for (int c = 0; c < PD_CH_HEAT; ++c)
@@ -249,14 +249,16 @@ __device__ __forceinline__ void filter_slack(double thr, float absmax, float* th
 // Active cells: one workgroup per (part, image) plane.
 // ---------------------------------------------------------------------------------
 struct CellArgs {
-    const float* lo;  // planar copy (B, 19, h, w)
+    const float* lo;    // planar copy (B, 19, h, w): read, or -- with nhwc set -- written by this kernel
+    const float* nhwc;  // the network output (B, h, w, 19) itself, or NULL
+    float* planar_out;
+    int n_planes;
     int h, w, hc, wc;
     const float* by;  // [hc][8] bound weights, sources y-3 .. y+3
     const float* bx;  // [wc][8]
     const int32_t* regy;
     const int32_t* regx;
-    const float* absmax;  // [B]
-    float2* slack;        // [B] out: (thr_lo, e2) of the candidate test
+    float2* slack;        // [B * 18] out: (thr_lo, e2) of the candidate test of a plane
     double thr;
     int32_t* cells;       // KF_NSEG segments; interior-weight cells from the front of a segment, the others from its back
     int seg_cap;
@@ -268,9 +270,14 @@ __global__ void __launch_bounds__(256)
 k_cells(CellArgs a) {
     extern __shared__ __align__(16) float lds[];
     __shared__ int s_nr, s_ne, s_br, s_be;
+    __shared__ float s_red[4];
     const int tid = threadIdx.x;
-    const int part = blockIdx.x, b = blockIdx.y;
-    const int plane = b * PD_N_PARTS + part;
+    // the 18 planes of an image on one XCD (workgroup i runs on XCD i % 8): they read the same
+    // cache lines of the network output
+    const int per_xcd = gridDim.x / 8;
+    const int plane = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (plane >= a.n_planes) return;
+    const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
     const int h = a.h, w = a.w, hc = a.hc, wc = a.wc;
     float* A = lds;                       // [h][w] |src|, later the list of active cells
     float* V = A + (size_t)h * w;         // [h][wc] row sums
@@ -282,31 +289,47 @@ k_cells(CellArgs a) {
         s_nr = 0;
         s_ne = 0;
     }
-    // all loads of a round are issued before the first value is used
+    // all loads of a round are issued before the first value is used.  With the network output
+    // as the source (small maps) the plane is picked out of the (h, w, 19) pixels -- one value per
+    // 76 bytes, the lines are shared with the image's other planes through the L2 -- and its
+    // planar copy is written for the kernels that follow.
+    float m = 0.f;
+    const float* pix = a.nhwc ? a.nhwc + (size_t)b * h * w * PD_CH_HEAT + part : nullptr;
+    float* copy = a.nhwc ? a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w : nullptr;
     for (int i0 = 0; i0 < h * w; i0 += 256 * 8) {
         float t[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i = i0 + k * 256 + tid;
-            t[k] = i < h * w ? img[i] : 0.f;
+            t[k] = i < h * w ? (pix ? pix[(size_t)i * PD_CH_HEAT] : img[i]) : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i = i0 + k * 256 + tid;
-            if (i < h * w) A[i] = fabsf(t[k]);
+            if (i < h * w) {
+                A[i] = fabsf(t[k]);
+                m = fmaxf(m, fabsf(t[k]));
+                if (copy) copy[i] = t[k];
+            }
         }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((tid & 63) == 0) s_red[tid >> 6] = m;
     for (int i = tid; i < 8 * wc; i += 256) bxL[(i & 7) * wc + (i >> 3)] = a.bx[i];
     for (int i = tid; i < 8 * hc; i += 256) byL[i] = a.by[i];
     for (int i = tid; i < hc; i += 256) regL[i] = a.regy[i];
     for (int i = tid; i < wc; i += 256) regL[hc + i] = a.regx[i];
     __shared__ float s_slack[2];
+    __syncthreads();
     if (tid == 0) {  // a few dozen float64 instructions: one lane does them for the workgroup
+        // the smoothed map of a part is a function of its own plane only: the plane's maximum bounds
+        // the rounding of the float32 evaluation
         float t, e;
-        filter_slack(a.thr, a.absmax[b], &t, &e);
+        filter_slack(a.thr, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), &t, &e);
         s_slack[0] = t;
         s_slack[1] = e;
-        if (part == 0) a.slack[b] = make_float2(t, e);
+        a.slack[plane] = make_float2(t, e);
     }
     __syncthreads();
     const float thr_lo = s_slack[0];
@@ -382,7 +405,7 @@ struct CellFilterArgs {
     int h, w, H, W;
     const float* cy;  // [hc][72]
     const float* cx;  // [wc][72]
-    const float2* slack;   // [B] (thr_lo, e2)
+    const float2* slack;   // [B * 18] (thr_lo, e2) per plane
     const int32_t* cells;
     int seg_cap;
     const int32_t* n_reg;
@@ -454,7 +477,7 @@ __device__ __forceinline__ void load_cell(const CellFilterArgs& a, int e, int r,
     c.y = (e >> 7) & 127;
     c.x = e & 127;
     const int b = c.plane / PD_N_PARTS, part = c.plane - b * PD_N_PARTS;
-    const float2 sl = a.slack[b];
+    const float2 sl = a.slack[c.plane];
     c.thr_lo = sl.x;
     c.e2 = sl.y;
     if (r < 9) {
@@ -828,8 +851,15 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     c.bx = c.by + (size_t)8 * hc;
     c.regy = ctx->kf_reg;
     c.regx = ctx->kf_reg + hc;
-    c.absmax = ctx->absmax;
-    c.slack = (float2*)(ctx->absmax + ctx->cfg.max_batch);
+    c.slack = ctx->plane_slack;
+    c.n_planes = (int)planes;
+    // Small maps: the active-cell kernel reads the network output itself and leaves the planar
+    // copy behind (one launch fewer; the decode of a small batch is bound by launch latency).
+    // Large maps: the strided reads would pull every cache line through the L2 eighteen times,
+    // so the copy is made first, by a kernel that reads and writes coalesced.
+    const bool gather = (size_t)h * w <= 4096;
+    c.nhwc = gather ? ctx->lo_heat : nullptr;
+    c.planar_out = ctx->heat_planar;
     c.thr = thr;
     c.cells = ctx->cells;
     c.seg_cap = (int)seg_cap;
@@ -844,7 +874,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     f.W = W;
     f.cy = tab;
     f.cx = tab + (size_t)72 * hc;
-    f.slack = (const float2*)(ctx->absmax + ctx->cfg.max_batch);
+    f.slack = ctx->plane_slack;
     f.cells = ctx->cells;
     f.seg_cap = c.seg_cap;
     f.n_reg = c.n_reg;
@@ -855,13 +885,15 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     f.cand_n = counters;
     f.CK = CK;
 
-    // cand_count, the list counters and absmax were cleared together with raw_count
-    pd_prof_begin(ctx, PD_STAGE_PLANAR);
-    hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
-                       h * w, ctx->heat_planar, (unsigned int*)ctx->absmax);
-    pd_prof_end(ctx);
+    // cand_count and the list counters were cleared together with raw_count
+    if (!gather) {
+        pd_prof_begin(ctx, PD_STAGE_PLANAR);
+        hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
+                           h * w, ctx->heat_planar, (unsigned int*)nullptr);
+        pd_prof_end(ctx);
+    }
     pd_prof_begin(ctx, PD_STAGE_CELLS);
-    hipLaunchKernelGGL(k_cells, dim3(PD_N_PARTS, B), dim3(256),
+    hipLaunchKernelGGL(k_cells, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(256),
                        sizeof(float) * ((size_t)h * w + (size_t)h * wc + 9 * (size_t)(hc + wc)), ctx->stream, c);
     pd_prof_end(ctx);
     // the list lengths are only known on the device: fixed grids stride over them
