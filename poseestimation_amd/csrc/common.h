@@ -181,6 +181,7 @@ struct pd_ctx {
     size_t paf_pairs_cap;
     int cand_cap;                    // CK
     // ---- peaks ----
+    int peaks_sorted;    // the peak stage has ordered the peaks itself: pd_launch_sort_peaks has nothing to do
     int32_t* zero_block; // raw_count | cand_count + list counters | absmax + slack: zero at the start of every decode
     size_t zero_bytes;
     int zero_clean;      // the block is zero (or a kernel that zeroes it is queued): pd_pack leaves it so
@@ -318,8 +319,9 @@ __device__ __forceinline__ float pd_bicubic_at(const float* __restrict__ img, in
 
 // ---- stage launchers (defined in the .hip files) --------------------------------
 int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed);
+// finish != 0 (only with only_over): one workgroup per image redoes the listed planes and orders the peaks
 int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smoothed,
-                           const int32_t* only_over, int over_limit);
+                           const int32_t* only_over, int over_limit, int finish = 0);
 // PD_E_STATE when the geometry has no filter tables (caller falls back)
 int pd_launch_peaks_filtered(pd_ctx* ctx, double thr);
 int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr);

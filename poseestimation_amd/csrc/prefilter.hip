@@ -931,8 +931,8 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     hipLaunchKernelGGL(k_verify<false>, dim3(vblocks), dim3(256), 0, ctx->stream, v);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
-    // planes whose candidates did not fit
-    return pd_launch_stream_exact(ctx, thr, 0, nullptr, ctx->cand_count, CK);
+    // planes whose candidates did not fit; the same kernel then orders every image's peaks
+    return pd_launch_stream_exact(ctx, thr, 0, nullptr, ctx->cand_count, CK, 1);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1178,5 +1178,5 @@ int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr) {
     hipLaunchKernelGGL(k_verify<true>, dim3(vblocks), dim3(256), 0, ctx->stream, v);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
-    return pd_launch_stream_exact(ctx, thr, 0, nullptr, ctx->cand_count, CK);
+    return pd_launch_stream_exact(ctx, thr, 0, nullptr, ctx->cand_count, CK, 1);
 }

@@ -7,7 +7,10 @@
 // axis 1 (x); borders by half-sample reflection; a float32 source is rounded to
 // float32 after each axis.  NMS compares with >= against the four neighbours,
 // out-of-image neighbours count as 0.0, and requires value > threshold.
+#include <stdlib.h>
+
 #include "colloader.h"
+#include "peaksort.h"
 
 #pragma clang fp contract(off)
 
@@ -24,6 +27,7 @@ struct SmoothArgs {
     // processed (planes the candidate filter could not hold)
     const int32_t* only_over;
     int over_limit;
+    SortArgs sort;  // k_finish_peaks: what the ordering of the peaks needs
 };
 
 __device__ __forceinline__ void emit_peak(bool is_peak, int y, int x, double score, RawPeak* list,
@@ -115,13 +119,43 @@ __device__ __forceinline__ void row_step(const SmoothArgs& a, ColLoader<SRC>& ld
 }
 
 template <int SRC>
+__device__ __forceinline__ void stream_plane(const SmoothArgs& a, double* ybuf, double* sbuf, int b, int part, int strip);
+
+template <int SRC>
 __global__ void __launch_bounds__(NTMAX)
 k_smooth_nms_stream(SmoothArgs a) {
     __shared__ double ybuf[2 * (NTMAX + 2 * PD_GR)];
     __shared__ double sbuf[2 * (NTMAX + 2)];
-    const int H = a.src.H, W = a.src.W;
     const int b = blockIdx.z, part = blockIdx.y, strip = blockIdx.x;
     if (a.only_over != nullptr && a.only_over[b * PD_N_PARTS + part] <= a.over_limit) return;
+    stream_plane<SRC>(a, ybuf, sbuf, b, part, strip);
+}
+
+// The end of the filtered peak stage, one workgroup per image: planes whose candidate list
+// overflowed (plateaus; rare) are redone here with the exact streaming pass, strip by strip,
+// then the image's peaks are ordered.  Everything an image needs is written and read by its
+// own workgroup, so barriers are all the synchronisation there is.
+template <int SRC>
+__global__ void __launch_bounds__(NTMAX)
+k_finish_peaks(SmoothArgs a) {
+    __shared__ double ybuf[2 * (NTMAX + 2 * PD_GR)];
+    __shared__ double sbuf[2 * (NTMAX + 2)];
+    __shared__ SortShared s_sort;
+    const int b = blockIdx.x;
+    for (int part = 0; part < PD_N_PARTS; ++part) {
+        if (a.only_over[b * PD_N_PARTS + part] <= a.over_limit) continue;  // uniform over the workgroup
+        for (int strip = 0; strip < a.n_strips; ++strip) {
+            __syncthreads();
+            stream_plane<SRC>(a, ybuf, sbuf, b, part, strip);
+        }
+    }
+    __syncthreads();
+    pd_sort_image(a.sort, s_sort, b, threadIdx.x, blockDim.x);
+}
+
+template <int SRC>
+__device__ __forceinline__ void stream_plane(const SmoothArgs& a, double* ybuf, double* sbuf, int b, int part, int strip) {
+    const int H = a.src.H, W = a.src.W;
     const int x0 = strip * a.strip_w;
     const int x1 = min(W, x0 + a.strip_w);
     const int xs = max(0, x0 - (PD_GR + 1));
@@ -256,7 +290,7 @@ static void pick_strips(int W, int* n_strips, int* strip_w, int* nt) {
 // The exact streaming kernel over all planes, or (only_over != NULL) over the planes
 // whose candidate count exceeded over_limit.
 int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smoothed,
-                           const int32_t* only_over, int over_limit) {
+                           const int32_t* only_over, int over_limit, int finish) {
     MapSource src = pd_heat_source(ctx);
     SmoothArgs a;
     a.src = src;
@@ -271,6 +305,20 @@ int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smo
     a.dbg = dbg_smoothed;
     a.only_over = only_over;
     a.over_limit = over_limit;
+    memset(&a.sort, 0, sizeof(a.sort));
+    static const bool separate_sort = getenv("PD_SEPARATE_SORT") != nullptr;  // comparison runs
+    if (finish && only_over != nullptr && dbg_smoothed == nullptr && !separate_sort) {
+        pd_fill_sort_args(ctx, &a.sort);
+        ctx->peaks_sorted = 1;
+        pd_prof_begin(ctx, PD_STAGE_SMOOTH_NMS);
+        if (src.kind == PD_SRC_LOWRES)
+            hipLaunchKernelGGL(k_finish_peaks<PD_SRC_LOWRES>, dim3(ctx->B), dim3(nt), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(k_finish_peaks<PD_SRC_FULLRES>, dim3(ctx->B), dim3(nt), 0, ctx->stream, a);
+        pd_prof_end(ctx);
+        PD_HIP(ctx, hipGetLastError());
+        return PD_OK;
+    }
     dim3 grid(a.n_strips, PD_N_PARTS, ctx->B);
     pd_prof_begin(ctx, PD_STAGE_SMOOTH_NMS);
     if (src.kind == PD_SRC_LOWRES)
