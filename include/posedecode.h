@@ -179,18 +179,18 @@ int pd_packed_device(pd_ctx* ctx, void** peaks, void** conns, void** persons, vo
  * milliseconds and the number of launches since the last read. */
 enum {
     PD_STAGE_RESIZE = 0,     /* bicubic resize / average / layout kernels */
-    PD_STAGE_SMOOTH_NMS = 1, /* Gaussian + NMS + peak emission */
-    PD_STAGE_SORT = 2,       /* peak ordering and id assignment */
+    PD_STAGE_SMOOTH_NMS = 1, /* Gaussian + NMS + peak emission (exact kernel); in the filtered path: the
+                                redo of overflowing planes and the ordering of the peaks */
+    PD_STAGE_SORT = 2,       /* peak ordering and id assignment, where it is a kernel of its own */
     PD_STAGE_PAIRS = 3,      /* PAF line integrals */
     PD_STAGE_MATCH = 4,      /* per-limb sort + greedy matching */
     PD_STAGE_PARSE = 5,      /* person assembly */
     PD_STAGE_PACK = 6,       /* result packing */
-    PD_STAGE_FILTER = 7,     /* float32 candidate filter over the active cells with interior weights */
+    PD_STAGE_FILTER = 7,     /* float32 candidate filter (active cells, or every pixel of full-resolution maps) */
     PD_STAGE_VERIFY = 8,     /* exact float64 verification of the candidates */
-    PD_STAGE_PLANAR = 9,     /* (h, w, 19) -> planar copy of the heatmaps + max |v| */
+    PD_STAGE_PLANAR = 9,     /* (h, w, 19) -> planar copy of the heatmaps (maps beyond 4096 pixels only) */
     PD_STAGE_CELLS = 10,     /* active-cell scan at network resolution */
-    PD_STAGE_FILTER_BORDER = 11, /* unused: the border cells are part of PD_STAGE_FILTER */
-    PD_N_STAGES = 12
+    PD_N_STAGES = 11
 };
 int pd_profile(pd_ctx* ctx, int enable);
 /* The same, restricted to the stages whose bit (1u << PD_STAGE_x) is set: timing one

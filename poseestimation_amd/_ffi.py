@@ -25,7 +25,7 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_decode_batch_static', 'pd_coco_rows', 'pd_image_resize_shape', 'pd_image_resize_pad', 'pd_render',
            'pd_debug_found', 'pd_comm_unique_id', 'pd_comm_create', 'pd_comm_destroy', 'pd_comm_last_error', 'pd_gather']
 
-STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells', 'filter_border']
+STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells']
 
 
 class Config(C.Structure):

@@ -99,7 +99,7 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     const size_t B = cfg->max_batch, PK = cfg->max_peaks_per_part;
     CR(dev_alloc(ctx, (void**)&ctx->raw, B * PD_N_PARTS * PK * sizeof(RawPeak)));
     // counters that start every decode at zero share one allocation and one memset
-    ctx->zero_bytes = (2 * B * PD_N_PARTS + 96 + 3 * B) * sizeof(int32_t);
+    ctx->zero_bytes = (2 * B * PD_N_PARTS + 96) * sizeof(int32_t);
     CR(dev_alloc(ctx, (void**)&ctx->zero_block, ctx->zero_bytes));
     CRH(hipMemset(ctx->zero_block, 0, ctx->zero_bytes));
     ctx->zero_clean = 1;
@@ -109,7 +109,6 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     CRH(hipMemset(ctx->fstats, 0, 4 * sizeof(int64_t)));
     ctx->raw_count = ctx->zero_block;
     ctx->cand_count = ctx->raw_count + B * PD_N_PARTS;                 // [B][18] + 3 x 32 list counters
-    ctx->absmax = (float*)(ctx->cand_count + B * PD_N_PARTS + 96);     // [B] max |v|, then [B] (thr_lo, e2)
     CR(dev_alloc(ctx, (void**)&ctx->pk_y, B * PD_N_PARTS * PK * sizeof(int32_t)));
     CR(dev_alloc(ctx, (void**)&ctx->pk_x, B * PD_N_PARTS * PK * sizeof(int32_t)));
     CR(dev_alloc(ctx, (void**)&ctx->pk_id, B * PD_N_PARTS * PK * sizeof(int32_t)));

@@ -173,7 +173,6 @@ struct pd_ctx {
     int32_t* cand_count;             // [B][18] candidates per plane | list length | cell counts
     float* full_absmax;              // [max_batch] max |value| of the full-resolution heatmaps per image (rounded up)
     int full_absmax_ok;              // full_absmax bounds the maps in full_heat
-    float* absmax;                   // [B] max |heat| per image
     float2* plane_slack;             // [max_batch * 18] (thr_lo, e2) of the candidate test, per plane
     float* heat_planar;              // (B, 19, h, w) copy of the network heatmaps
     size_t heat_planar_cap;
@@ -182,7 +181,7 @@ struct pd_ctx {
     int cand_cap;                    // CK
     // ---- peaks ----
     int peaks_sorted;    // the peak stage has ordered the peaks itself: pd_launch_sort_peaks has nothing to do
-    int32_t* zero_block; // raw_count | cand_count + list counters | absmax + slack: zero at the start of every decode
+    int32_t* zero_block; // raw_count | cand_count + list counters: zero at the start of every decode
     size_t zero_bytes;
     int zero_clean;      // the block is zero (or a kernel that zeroes it is queued): pd_pack leaves it so
     int64_t* fstats;     // what pd_filter_stats reports, summed up by k_sort_peaks before the counters go

@@ -145,11 +145,10 @@ extern "C" int pd_decode_batch_static(const float* heat, const float* paf, int B
     v->impl = PD_IMPL_STREAM;
     v->stream = (hipStream_t)stream;
     v->host_results = 1;
-    v->zero_bytes = (2 * NB * PD_N_PARTS + 96 + 3 * NB) * sizeof(int32_t);
+    v->zero_bytes = (2 * NB * PD_N_PARTS + 96) * sizeof(int32_t);
     v->zero_block = c.take<int32_t>(v->zero_bytes / sizeof(int32_t));
     v->raw_count = v->zero_block;
     v->cand_count = v->raw_count + NB * PD_N_PARTS;
-    v->absmax = (float*)(v->cand_count + NB * PD_N_PARTS + 96);
     v->fstats = c.take<int64_t>(4);
     v->raw = c.take<RawPeak>(NB * PD_N_PARTS * PK);
     v->pk_y = c.take<int32_t>(NB * PD_N_PARTS * PK);
