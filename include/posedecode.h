@@ -353,10 +353,10 @@ const char* pd_comm_last_error(pd_comm* comm);
  * those bytes, then one copy to recv_host.  On the root, recv_host receives the buffers
  * back to back (each starting 16-byte aligned) in rank-major, then context order -- the
  * image order of a batch sharded in contiguous blocks -- and sizes[rank * n_ctx + i]
- * their lengths; *total_bytes is the room they take (also when recv_capacity is too
- * small: PD_E_OVERFLOW, nothing received... every rank must then call again).  Waits for
- * the contexts' streams first and for the collect before it returns; n_ctx <= 16 and
- * equal on all ranks. */
+ * their lengths; *total_bytes is the room they take.  A recv_capacity that is too small
+ * is reported by PD_E_OVERFLOW on the root after the exchange has completed on every rank
+ * (nothing is copied to recv_host; the other ranks return PD_OK).  Waits for the contexts'
+ * streams first and for the collect before it returns; n_ctx <= 16 and equal on all ranks. */
 int pd_gather(pd_comm* comm, pd_ctx* const* ctxs, int n_ctx, int root, void* recv_host,
               uint64_t recv_capacity, uint64_t* sizes, uint64_t* total_bytes);
 

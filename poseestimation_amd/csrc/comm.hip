@@ -182,6 +182,8 @@ extern "C" int pd_gather(pd_comm* c, pd_ctx* const* ctxs, int n_ctx, int root, v
     // every context's decode must have reached its skeleton buffer; its header gives the size
     int64_t mine[PD_GATHER_MAX_CTX];
     memset(mine, 0, sizeof(mine));
+    int short_ctx = -1;
+    long long short_need = 0;
     for (int i = 0; i < n_ctx; ++i) {
         pd_ctx* x = ctxs[i];
         if (!x || !x->skel_dst) CM_FAIL(c, PD_E_STATE, "pd_gather: context %d has no skeleton buffer (pd_set_skeleton_buffer)", i);
@@ -189,10 +191,15 @@ extern "C" int pd_gather(pd_comm* c, pd_ctx* const* ctxs, int n_ctx, int root, v
         CM_HIP(c, hipStreamSynchronize(x->stream));
         int64_t head[8];
         CM_HIP(c, hipMemcpy(head, x->skel_dst, sizeof(head), hipMemcpyDeviceToHost));
-        if (head[5] != 0)
-            CM_FAIL(c, PD_E_OVERFLOW, "pd_gather: context %d: its skeleton buffer holds %llu bytes, the results need %lld", i,
-                    (unsigned long long)x->skel_cap, (long long)head[5]);
-        mine[i] = (int64_t)blob_bytes(head);
+        if (head[5] != 0) {
+            // the buffer was too small for the payload: the header (which says so) and the count
+            // tables still travel, so that no rank is left waiting; reported after the exchange
+            short_ctx = i;
+            short_need = (long long)head[5];
+            mine[i] = (int64_t)pd_res_layout((int)head[0]).off_payload;
+        } else {
+            mine[i] = (int64_t)blob_bytes(head);
+        }
     }
     // 1. byte counts of every rank
     CM_HIP(c, hipMemcpyAsync(c->counts_dev + (size_t)c->rank * PD_GATHER_MAX_CTX, mine, sizeof(mine), hipMemcpyHostToDevice,
@@ -214,9 +221,8 @@ extern "C" int pd_gather(pd_comm* c, pd_ctx* const* ctxs, int n_ctx, int root, v
     if (total_bytes) *total_bytes = total;
     const bool is_root = c->rank == root;
     if (is_root) {
-        if (!recv_host || recv_capacity < total)
-            CM_FAIL(c, PD_E_OVERFLOW, "pd_gather: the gathered buffers take %llu bytes, room for %llu",
-                    (unsigned long long)total, (unsigned long long)recv_capacity);
+        // the root always takes part in the exchange (the other ranks are already committed to
+        // their sends); a host array that is too small is reported after it
         if (c->recv_cap < total) {
             if (c->recv_dev) CM_HIP(c, hipFree(c->recv_dev));
             c->recv_dev = nullptr;
@@ -239,7 +245,16 @@ extern "C" int pd_gather(pd_comm* c, pd_ctx* const* ctxs, int n_ctx, int root, v
             }
     }
     CM_RCCL(c, g_rccl.GroupEnd());
-    if (is_root) CM_HIP(c, hipMemcpyAsync(recv_host, c->recv_dev, total, hipMemcpyDeviceToHost, c->stream));
+    const bool fits = !is_root || (recv_host != nullptr && recv_capacity >= total);
+    if (is_root && fits) CM_HIP(c, hipMemcpyAsync(recv_host, c->recv_dev, total, hipMemcpyDeviceToHost, c->stream));
     CM_HIP(c, hipStreamSynchronize(c->stream));
+    if (short_ctx >= 0)
+        CM_FAIL(c, PD_E_OVERFLOW, "pd_gather: context %d: its skeleton buffer holds %llu bytes, the results need %lld "
+                                  "(header and count tables were sent)",
+                short_ctx, (unsigned long long)ctxs[short_ctx]->skel_cap, short_need);
+    if (!fits)
+        CM_FAIL(c, PD_E_OVERFLOW, "pd_gather: the gathered buffers take %llu bytes, room for %llu (the exchange itself "
+                                  "has completed on every rank)",
+                (unsigned long long)total, (unsigned long long)recv_capacity);
     return PD_OK;
 }

@@ -152,8 +152,8 @@ struct AvgArgs {
 };
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
-#define FT_TW 32        // output tile of a workgroup: FT_TW x FT_TH = 256 pixels
-#define FT_TH 8
+#define FT_TW 16        // output tile of a workgroup: FT_TW x FT_TH = 256 pixels
+#define FT_TH 16
 #define FT_CH 4         // channels per workgroup: they are adjacent in the (h, w, C) source, one 16-byte load
 #define FT_PATCH 1408   // x8-map pixels (four channels each) staged in LDS: a downscale up to about 2.1
 #define FT_HSUM 704     // horizontal sums (four channels each) staged in LDS
