@@ -465,7 +465,7 @@ def run_single(env):
                        'inputs': 'device-resident network outputs, %d distinct batches of %.1f MB used in turn '
                                  '(the host-to-device copy of predict.py:61 is outside the timed region; '
                                  'see host_inputs_images_per_s)' % (NBUF, B * n * 57 * 4 / 1e6),
-                       'outputs': 'full packed results (peaks, connection lists, person rows) copied to the host every decode'
+                       'outputs': 'full packed results (peaks, connection lists, person rows) stored to pinned host memory by the pack kernel of every decode'
                                   if gather is None else
                                   'peaks and person rows copied to the host once per round of %d decodes' % gather.n
                                   if not use_dist else

@@ -209,6 +209,7 @@ struct pd_ctx {
     unsigned char* res_host;
     size_t res_cap, res_spec, res_have;
     size_t res_user_cap;  // != 0: res_dev is a caller's buffer of this many bytes (the pack kernel checks it)
+    int pack_direct;      // the pack kernel stores the results to the pinned host mirror itself (no copy behind it)
     int have_peaks, have_conns, have_persons, packed;
     unsigned char* skel_dst;  // caller's device buffer for the skeleton copy of the results (or NULL)
     size_t skel_cap;

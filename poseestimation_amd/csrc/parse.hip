@@ -473,6 +473,8 @@ struct PackArgs {
     const pd_conn* conn;
     const double* persons;
     unsigned char* res;  // result buffer: header | count tables | peaks | conns | persons
+    unsigned char* res2; // or NULL: a second copy of every byte, written as it is produced (the
+                         // pinned host mirror, stored to over PCIe: no copy kernel behind the pack)
     unsigned long long cap;  // bytes behind res, 0 = large enough by construction
     ResLayout lay;
     int32_t* zero;           // counters to clear for the next decode (or NULL)
@@ -537,24 +539,32 @@ k_pack(PackArgs a) {
     const unsigned long long need = a.lay.off_payload + (unsigned long long)s_tot[3] * sizeof(pd_peak) +
                                     (unsigned long long)s_tot[4] * sizeof(pd_conn) + (unsigned long long)s_tot[5] * 20 * sizeof(double);
     const bool fits = a.cap == 0 || need <= a.cap;
+    const long long mirror = a.res2 ? a.res2 - a.res : 0;  // byte distance to the second copy
+#define PD_PUT(ptr, value)                                                              \
+    do {                                                                                \
+        auto* p_ = (ptr);                                                               \
+        const auto v_ = (value);                                                        \
+        *p_ = v_;                                                                       \
+        if (a.res2) *(decltype(p_))((unsigned char*)p_ + mirror) = v_;                  \
+    } while (0)
     if (b == 0 && tid == 0) {
         int64_t* head = (int64_t*)a.res;
         const int fb = min(min(s_redbad[0], s_redbad[1]), min(s_redbad[2], s_redbad[3]));
-        head[0] = a.B;
-        head[1] = s_tot[3];
-        head[2] = s_tot[4];
-        head[3] = s_tot[5];
-        head[4] = fb == 0x7fffffff ? -1 : fb;
-        head[5] = fits ? 0 : (int64_t)need;  // != 0: the buffer is too small, no payload was written
+        PD_PUT(head + 0, (int64_t)a.B);
+        PD_PUT(head + 1, (int64_t)s_tot[3]);
+        PD_PUT(head + 2, (int64_t)s_tot[4]);
+        PD_PUT(head + 3, (int64_t)s_tot[5]);
+        PD_PUT(head + 4, (int64_t)(fb == 0x7fffffff ? -1 : fb));
+        PD_PUT(head + 5, (int64_t)(fits ? 0 : (int64_t)need));  // != 0: the buffer is too small, no payload was written
     }
     // count tables of this image
     if (tid < PD_N_PARTS)
-        ((int32_t*)(a.res + a.lay.off_part))[b * PD_N_PARTS + tid] = a.have_peaks ? a.part_count[b * PD_N_PARTS + tid] : 0;
+        PD_PUT((int32_t*)(a.res + a.lay.off_part) + b * PD_N_PARTS + tid, a.have_peaks ? a.part_count[b * PD_N_PARTS + tid] : 0);
     if (tid < PD_N_LIMBS)
-        ((int32_t*)(a.res + a.lay.off_limb))[b * PD_N_LIMBS + tid] = a.have_conns ? a.limb_count[b * PD_N_LIMBS + tid] : 0;
+        PD_PUT((int32_t*)(a.res + a.lay.off_limb) + b * PD_N_LIMBS + tid, a.have_conns ? a.limb_count[b * PD_N_LIMBS + tid] : 0);
     if (tid == 0) {
-        ((int32_t*)(a.res + a.lay.off_pers))[b] = a.have_persons ? a.person_count[b] : 0;
-        ((int32_t*)(a.res + a.lay.off_stat))[b] = a.status[b];
+        PD_PUT((int32_t*)(a.res + a.lay.off_pers) + b, a.have_persons ? a.person_count[b] : 0);
+        PD_PUT((int32_t*)(a.res + a.lay.off_stat) + b, a.status[b]);
     }
     const long long n_peaks = s_tot[3], n_conns = s_tot[4];
     pd_peak* out_peaks = (pd_peak*)(a.res + a.lay.off_payload) + s_tot[0];
@@ -571,7 +581,7 @@ k_pack(PackArgs a) {
             q.y = a.pk_y[o];
             q.x = a.pk_x[o];
             q.score = a.pk_score[o];
-            out_peaks[i] = q;
+            PD_PUT(out_peaks + i, q);
         }
     }
     if (a.have_conns && fits) {
@@ -579,14 +589,15 @@ k_pack(PackArgs a) {
         for (int i = tid; i < n; i += 256) {
             int k = 0;
             while (i >= s_lbase[k + 1]) ++k;
-            out_conns[i] = a.conn[((size_t)b * PD_N_LIMBS + k) * a.PK + (i - s_lbase[k])];
+            PD_PUT(out_conns + i, a.conn[((size_t)b * PD_N_LIMBS + k) * a.PK + (i - s_lbase[k])]);
         }
     }
     if (a.have_persons && fits) {
         const int n = a.person_count[b] * 20;
         const double* src = a.persons + (size_t)b * a.max_persons * 20;
-        for (int i = tid; i < n; i += 256) out_persons[i] = src[i];
+        for (int i = tid; i < n; i += 256) PD_PUT(out_persons + i, src[i]);
     }
+#undef PD_PUT
 }
 
 int pd_launch_parse(pd_ctx* ctx) {
@@ -637,6 +648,7 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.conn = ctx->conn;
     a.persons = ctx->persons;
     a.res = ctx->res_dev;
+    a.res2 = ctx->pack_direct && ctx->res_user_cap == 0 ? ctx->res_host : nullptr;
     a.cap = ctx->res_user_cap;
     a.lay = pd_res_layout(ctx->B);
     a.zero = ctx->zero_block;
@@ -649,6 +661,7 @@ int pd_launch_pack(pd_ctx* ctx) {
     if (ctx->skel_dst) {
         // the caller's device buffer gets the same layout without the connection lists
         a.res = ctx->skel_dst;
+        a.res2 = nullptr;
         a.cap = ctx->skel_cap;
         a.have_conns = 0;
         hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
