@@ -67,6 +67,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the untimed extra passes (per-stage times, dense kernel, host-resident inputs)')
     ap.add_argument('--people', type=int, default=0, help='experiments: fixed people per image')
+    ap.add_argument('--no-stage-timing', action='store_true',
+                    help='experiments: no event pair around the roofline kernel in the timed region')
     ap.add_argument('--contexts', type=int, default=0,
                     help='decode contexts (HIP streams) per GPU, used round-robin (0: 4; 1 for the multi-scale workload, whose kernels fill the chip by themselves)')
     ap.add_argument('--pipeline', default='', choices=['', 'fetch', 'rounds'],
@@ -309,7 +311,7 @@ def run_single(env):
     gc.collect()
     gc.freeze()
     for e in engs:
-        e.ctx.profile(stages=[ROOF_STAGE])
+        e.ctx.profile(stages=[] if args.no_stage_timing else [ROOF_STAGE])
     # every context reaches its recorded launch sequences (third identical call per input
     # buffer and skeleton slice); with a process group, the first gathers also set up RCCL's
     # channels and the launcher threads

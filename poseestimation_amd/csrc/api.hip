@@ -71,7 +71,9 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     ctx->impl = PD_IMPL_FAST;
     ctx->use_graph = getenv("PD_NO_GRAPH") ? 0 : 1;
     ctx->host_results = 1;
-    ctx->pack_direct = getenv("PD_PACK_COPY") ? 0 : 1;  // PD_PACK_COPY=1: a device-to-host copy behind the pack instead
+    // PD_PACK_COPY=1: always a device-to-host copy behind the pack; PD_PACK_DIRECT=1: never
+    ctx->pack_policy = getenv("PD_PACK_COPY") ? 0 : (getenv("PD_PACK_DIRECT") ? 1 : -1);
+    ctx->pack_direct = ctx->pack_policy != 0;
 #define CR(call)                                                                     \
     do {                                                                             \
         int rc_ = (call);                                                            \
@@ -235,6 +237,8 @@ MapSource pd_paf_source(const pd_ctx* ctx) {
 static void reset_results(pd_ctx* ctx) {
     ctx->have_peaks = ctx->have_conns = ctx->have_persons = ctx->packed = 0;
 }
+
+#define PD_PACK_DIRECT_LIMIT ((size_t)1 << 20)  // bytes of packed results up to which the pack kernel writes the host mirror
 
 static int check_batch(pd_ctx* ctx, int B, int H, int W, const char* who) {
     if (B < 1 || B > ctx->cfg.max_batch) PD_FAIL(ctx, PD_E_INVALID, "%s: batch %d exceeds max_batch %d", who, B, ctx->cfg.max_batch);
@@ -727,6 +731,7 @@ static int finish_results(pd_ctx* ctx) {
         ctx->res_have = end;
     }
     if (ctx->pack_direct) ctx->res_have = end;  // what pd_results_host reports: the bytes in use
+    ctx->last_result_bytes = end;
     return PD_OK;
 }
 
@@ -746,14 +751,19 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     if (!heat || !paf) PD_FAIL(ctx, PD_E_INVALID, "pd_decode_batch: heat and paf are required");
     int rc = pd_set_lowres(ctx, heat, paf, B, h, w, H, W, mem);
     if (rc != PD_OK) return rc;
-    if (mem != PD_MEM_DEVICE || !ctx->use_graph) return pd_decode_fullres(ctx, thre1, thre2);
+    if (mem != PD_MEM_DEVICE || !ctx->use_graph) {
+        if (ctx->pack_policy < 0) ctx->pack_direct = ctx->last_result_bytes <= PD_PACK_DIRECT_LIMIT;
+        return pd_decode_fullres(ctx, thre1, thre2);
+    }
 
     // Device-resident input: the whole launch sequence (about a dozen kernels, three
     // memsets, the result copy and, when profiling, the event pairs) is captured into a
     // HIP graph the second time the same call is seen and replayed from then on, which
     // takes the per-launch host cost out of the steady state.
+    if (ctx->pack_policy < 0) ctx->pack_direct = ctx->last_result_bytes <= PD_PACK_DIRECT_LIMIT;
     GraphKey key;
     memset(&key, 0, sizeof(key));
+    key.pack_direct = ctx->pack_direct;
     key.heat = heat;
     key.paf = paf;
     key.B = B;

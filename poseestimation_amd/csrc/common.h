@@ -95,6 +95,7 @@ struct GraphKey {
     int mode, impl;
     uint32_t prof;
     int host_results;
+    int pack_direct;
     const void* skel;
     uint64_t skel_cap;
     uint64_t gen;  // pd_ctx::gen at the time: any device buffer or table a launch refers to that was
@@ -209,7 +210,12 @@ struct pd_ctx {
     unsigned char* res_host;
     size_t res_cap, res_spec, res_have;
     size_t res_user_cap;  // != 0: res_dev is a caller's buffer of this many bytes (the pack kernel checks it)
-    int pack_direct;      // the pack kernel stores the results to the pinned host mirror itself (no copy behind it)
+    // The pack kernel stores the results to the pinned host mirror itself (no copy node behind a
+    // decode) while results are small; megabytes of results per decode go faster through a copy
+    // that overlaps with the kernels of other contexts.  pack_policy: -1 by the size of the last
+    // results, 0 always copy, 1 always direct; pack_direct: what the next pack does.
+    int pack_policy, pack_direct;
+    size_t last_result_bytes;
     int have_peaks, have_conns, have_persons, packed;
     unsigned char* skel_dst;  // caller's device buffer for the skeleton copy of the results (or NULL)
     size_t skel_cap;

@@ -266,12 +266,16 @@ struct CellArgs {
     int32_t* n_edge;      // [KF_NSEG]
 };
 
-__global__ void __launch_bounds__(256)
+// 256 threads for small planes, 512 for large ones (a workgroup's time is a chain of dependent
+// phases: more threads shorten every phase, and the planes of a large map leave room for few
+// workgroups per CU).
+__global__ void __launch_bounds__(1024)
 k_cells(CellArgs a) {
     extern __shared__ __align__(16) float lds[];
     __shared__ int s_nr, s_ne, s_br, s_be;
-    __shared__ float s_red[4];
+    __shared__ float s_red[16];
     const int tid = threadIdx.x;
+    const int NT = blockDim.x;
     // the 18 planes of an image on one XCD (workgroup i runs on XCD i % 8): they read the same
     // cache lines of the network output
     const int per_xcd = gridDim.x / 8;
@@ -296,16 +300,16 @@ k_cells(CellArgs a) {
     float m = 0.f;
     const float* pix = a.nhwc ? a.nhwc + (size_t)b * h * w * PD_CH_HEAT + part : nullptr;
     float* copy = a.nhwc ? a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w : nullptr;
-    for (int i0 = 0; i0 < h * w; i0 += 256 * 8) {
+    for (int i0 = 0; i0 < h * w; i0 += NT * 8) {
         float t[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int i = i0 + k * 256 + tid;
+            const int i = i0 + k * NT + tid;
             t[k] = i < h * w ? (pix ? pix[(size_t)i * PD_CH_HEAT] : img[i]) : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int i = i0 + k * 256 + tid;
+            const int i = i0 + k * NT + tid;
             if (i < h * w) {
                 A[i] = fabsf(t[k]);
                 m = fmaxf(m, fabsf(t[k]));
@@ -316,17 +320,19 @@ k_cells(CellArgs a) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     if ((tid & 63) == 0) s_red[tid >> 6] = m;
-    for (int i = tid; i < 8 * wc; i += 256) bxL[(i & 7) * wc + (i >> 3)] = a.bx[i];
-    for (int i = tid; i < 8 * hc; i += 256) byL[i] = a.by[i];
-    for (int i = tid; i < hc; i += 256) regL[i] = a.regy[i];
-    for (int i = tid; i < wc; i += 256) regL[hc + i] = a.regx[i];
+    for (int i = tid; i < 8 * wc; i += NT) bxL[(i & 7) * wc + (i >> 3)] = a.bx[i];
+    for (int i = tid; i < 8 * hc; i += NT) byL[i] = a.by[i];
+    for (int i = tid; i < hc; i += NT) regL[i] = a.regy[i];
+    for (int i = tid; i < wc; i += NT) regL[hc + i] = a.regx[i];
     __shared__ float s_slack[2];
     __syncthreads();
     if (tid == 0) {  // a few dozen float64 instructions: one lane does them for the workgroup
         // the smoothed map of a part is a function of its own plane only: the plane's maximum bounds
         // the rounding of the float32 evaluation
         float t, e;
-        filter_slack(a.thr, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), &t, &e);
+        float pm = 0.f;
+        for (int q = 0; q < (NT >> 6); ++q) pm = fmaxf(pm, s_red[q]);
+        filter_slack(a.thr, pm, &t, &e);
         s_slack[0] = t;
         s_slack[1] = e;
         a.slack[plane] = make_float2(t, e);
@@ -334,7 +340,7 @@ k_cells(CellArgs a) {
     __syncthreads();
     const float thr_lo = s_slack[0];
     // thread = (cell column x, row lane): weights and clamped taps of the column stay in registers
-    const int lanes = 256 / wc;  // wc <= 128
+    const int lanes = NT / wc;  // wc <= 128
     const int x = tid % wc, rl = tid / wc;
     if (rl < lanes) {
         float k[7];
@@ -393,8 +399,8 @@ k_cells(CellArgs a) {
     __syncthreads();
     // every cell is listed at most once and a segment has room for all cells of its planes
     int32_t* segment = a.cells + (size_t)seg * a.seg_cap;
-    for (int i = tid; i < nr; i += 256) segment[s_br + i] = list[i];
-    for (int i = tid; i < ne; i += 256) segment[a.seg_cap - 1 - (s_be + i)] = list[hc * wc - 1 - i];
+    for (int i = tid; i < nr; i += NT) segment[s_br + i] = list[i];
+    for (int i = tid; i < ne; i += NT) segment[a.seg_cap - 1 - (s_be + i)] = list[hc * wc - 1 - i];
 }
 
 // ---------------------------------------------------------------------------------
@@ -892,8 +898,9 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
                            h * w, ctx->heat_planar, (unsigned int*)nullptr);
         pd_prof_end(ctx);
     }
+    static const int cells_nt = getenv("PD_CELLS_THREADS") ? atoi(getenv("PD_CELLS_THREADS")) : 0;  // comparison runs
     pd_prof_begin(ctx, PD_STAGE_CELLS);
-    hipLaunchKernelGGL(k_cells, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(256),
+    hipLaunchKernelGGL(k_cells, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(cells_nt > 0 ? cells_nt : (gather ? 256 : 512)),
                        sizeof(float) * ((size_t)h * w + (size_t)h * wc + 9 * (size_t)(hc + wc)), ctx->stream, c);
     pd_prof_end(ctx);
     // the list lengths are only known on the device: fixed grids stride over them

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from poseestimation_amd import synth
 from poseestimation_amd.predict_decode import DecodeEngine
-B, H, W = 64, 368, 368
+B, H, W = int(os.environ.get('PD_HC_BATCH', '64')), 368, 368
 NC = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 heat, paf = synth.batch(B, H, W, (1, 8), seed0=0, paf_order='xy')
 dh, dp = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 tq, tf = [0.0], [0.0]
 N = 400
 t0 = time.perf_counter(); run(N, tq, tf); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print('contexts', NC, 'us/step total', dt / N * 1e6, 'enqueue', tq[0] / N * 1e6, 'fetch', tf[0] / N * 1e6)
+print('batch', B, 'contexts', NC, 'us/step total', dt / N * 1e6, 'enqueue', tq[0] / N * 1e6, 'fetch', tf[0] / N * 1e6)
 # enqueue only (no fetch) to see the pure launch cost
 torch.cuda.synchronize()
 t0 = time.perf_counter()
