@@ -266,40 +266,41 @@ struct CellArgs {
     int32_t* n_edge;      // [KF_NSEG]
 };
 
-// 256 threads for small planes, 512 for large ones (a workgroup's time is a chain of dependent
-// phases: more threads shorten every phase, and the planes of a large map leave room for few
-// workgroups per CU).
-__global__ void __launch_bounds__(1024)
+// One workgroup per (part, image) plane.  Once the plane is in LDS every thread owns a cell
+// column and a band of cell rows: it walks down the band with the seven row sums of the y
+// window in registers and notes its active cells as bit masks, so that the only workgroup
+// barriers are the one behind the load and the two around the reservation of list space.
+// 256 threads for small planes, 512 for large ones.
+__global__ void __launch_bounds__(512)
 k_cells(CellArgs a) {
     extern __shared__ __align__(16) float lds[];
-    __shared__ int s_nr, s_ne, s_br, s_be;
-    __shared__ float s_red[16];
-    const int tid = threadIdx.x;
-    const int NT = blockDim.x;
+    __shared__ float s_red[8];
+    __shared__ int s_cnt[8][2];
+    __shared__ int s_base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_waves = blockDim.x >> 6;
     // the 18 planes of an image on one XCD (workgroup i runs on XCD i % 8): they read the same
     // cache lines of the network output
     const int per_xcd = gridDim.x / 8;
     const int plane = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (plane >= a.n_planes) return;
     const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
-    const int h = a.h, w = a.w, hc = a.hc, wc = a.wc;
-    float* A = lds;                       // [h][w] |src|, later the list of active cells
-    float* V = A + (size_t)h * w;         // [h][wc] row sums
-    float* bxL = V + (size_t)h * wc;      // [8][wc]: lanes with consecutive x read consecutive words
-    float* byL = bxL + (size_t)8 * wc;    // [hc][8]
-    int* regL = (int*)(byL + (size_t)8 * hc);  // [hc] | [wc]
+    const int h = a.h, w = a.w;
+    const int hc = a.hc, wc = a.wc;  // cells of 8 x 8 output pixels: hc <= h, wc <= w
+    // thread = (cell column x, band of cell rows): as many bands as the workgroup has whole rows of threads
+    const int bands = blockDim.x / wc;
+    const int rows_per = (hc + bands - 1) / bands;  // <= 32: the masks below hold a bit per row
+    const int x = tid % wc, band = tid / wc;
+    const int ya = min(hc, band * rows_per), yb = band < bands ? min(hc, ya + rows_per) : ya;
+    float* A = lds;  // [h][w] |v| of the plane
+    // ---- the plane: |v| to LDS, its maximum, its planar copy (small maps: the plane is picked
+    // out of the (h, w, 19) pixels, one value per 76 bytes; the lines are shared with the image's
+    // other planes through the L2).  All loads of a round are issued before the first value is used.
     const float* img = a.lo + ((size_t)b * PD_CH_HEAT + part) * h * w;
-    if (tid == 0) {
-        s_nr = 0;
-        s_ne = 0;
-    }
-    // all loads of a round are issued before the first value is used.  With the network output
-    // as the source (small maps) the plane is picked out of the (h, w, 19) pixels -- one value per
-    // 76 bytes, the lines are shared with the image's other planes through the L2 -- and its
-    // planar copy is written for the kernels that follow.
-    float m = 0.f;
     const float* pix = a.nhwc ? a.nhwc + (size_t)b * h * w * PD_CH_HEAT + part : nullptr;
     float* copy = a.nhwc ? a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w : nullptr;
+    const int NT = blockDim.x;
+    float m = 0.f;
     for (int i0 = 0; i0 < h * w; i0 += NT * 8) {
         float t[8];
 #pragma unroll
@@ -319,57 +320,52 @@ k_cells(CellArgs a) {
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((tid & 63) == 0) s_red[tid >> 6] = m;
-    for (int i = tid; i < 8 * wc; i += NT) bxL[(i & 7) * wc + (i >> 3)] = a.bx[i];
-    for (int i = tid; i < 8 * hc; i += NT) byL[i] = a.by[i];
-    for (int i = tid; i < hc; i += NT) regL[i] = a.regy[i];
-    for (int i = tid; i < wc; i += NT) regL[hc + i] = a.regx[i];
-    __shared__ float s_slack[2];
+    if (lane == 0) s_red[wv] = m;
     __syncthreads();
-    if (tid == 0) {  // a few dozen float64 instructions: one lane does them for the workgroup
-        // the smoothed map of a part is a function of its own plane only: the plane's maximum bounds
-        // the rounding of the float32 evaluation
-        float t, e;
-        float pm = 0.f;
-        for (int q = 0; q < (NT >> 6); ++q) pm = fmaxf(pm, s_red[q]);
-        filter_slack(a.thr, pm, &t, &e);
-        s_slack[0] = t;
-        s_slack[1] = e;
-        a.slack[plane] = make_float2(t, e);
+    // the smoothed map of a part is a function of its own plane only: the plane's maximum bounds
+    // the rounding of the float32 evaluation.  A few dozen float64 instructions, one lane per
+    // wavefront does them.
+    float thr_lo = 0.f;
+    if (lane == 0) {
+        float pm = 0.f, e2;
+        for (int q = 0; q < n_waves; ++q) pm = fmaxf(pm, s_red[q]);
+        filter_slack(a.thr, pm, &thr_lo, &e2);
+        if (wv == 0) a.slack[plane] = make_float2(thr_lo, e2);
     }
-    __syncthreads();
-    const float thr_lo = s_slack[0];
-    // thread = (cell column x, row lane): weights and clamped taps of the column stay in registers
-    const int lanes = NT / wc;  // wc <= 128
-    const int x = tid % wc, rl = tid / wc;
-    if (rl < lanes) {
-        float k[7];
-        int c[7];
+    thr_lo = __shfl(thr_lo, 0);
+    // ---- the bound U of every cell of the thread's band
+    unsigned m_reg = 0u, m_edge = 0u;
+    if (yb > ya) {
+        float kx[7];
+        int cx[7];
 #pragma unroll
         for (int p = 0; p < 7; ++p) {
-            k[p] = bxL[p * wc + x];
-            c[p] = pd_clampi(x - 3 + p, 0, w - 1);
+            kx[p] = a.bx[8 * x + p];
+            cx[p] = pd_clampi(x - 3 + p, 0, w - 1);
         }
-        for (int s0 = rl; s0 < h; s0 += lanes) {
-            const float* row = A + (size_t)s0 * w;
-            float v = k[0] * row[c[0]];
-#pragma unroll
-            for (int p = 1; p < 7; ++p) v = fmaf(k[p], row[c[p]], v);
-            V[(size_t)s0 * wc + x] = v;
-        }
-    }
-    __syncthreads();
-    int* list = (int*)A;  // hc * wc <= h * w entries
-    if (rl < lanes) {
-        // a run of consecutive cell rows per thread, the seven row sums it needs sliding through registers
-        const int per = (hc + lanes - 1) / lanes;
-        const int y0 = rl * per, y1 = min(hc, y0 + per);
+        const int regx = a.regx[x];
         float win[7];
+        win[0] = 0.f;
+        // the window of cell row y is the row sums of map rows y-3 .. y+3, clamped to the map
 #pragma unroll
-        for (int p = 0; p < 7; ++p) win[p] = V[(size_t)pd_clampi(y0 - 3 + p, 0, h - 1) * wc + x];
-        const int regx = regL[hc + x];
-        for (int y = y0; y < y1; ++y) {
-            const float4 ka = *(const float4*)(byL + 8 * y), kb = *(const float4*)(byL + 8 * y + 4);
+        for (int q = 1; q < 7; ++q) {
+            const float* row = A + pd_clampi(ya - 4 + q, 0, h - 1) * w;
+            float v = kx[0] * row[cx[0]];
+#pragma unroll
+            for (int p = 1; p < 7; ++p) v = fmaf(kx[p], row[cx[p]], v);
+            win[q] = v;
+        }
+        for (int y = ya; y < yb; ++y) {
+#pragma unroll
+            for (int p = 0; p < 6; ++p) win[p] = win[p + 1];
+            {
+                const float* row = A + min(y + 3, h - 1) * w;
+                float v = kx[0] * row[cx[0]];
+#pragma unroll
+                for (int p = 1; p < 7; ++p) v = fmaf(kx[p], row[cx[p]], v);
+                win[6] = v;
+            }
+            const float4 ka = *(const float4*)(a.by + 8 * y), kb = *(const float4*)(a.by + 8 * y + 4);
             float u = ka.x * win[0];
             u = fmaf(ka.y, win[1], u);
             u = fmaf(ka.z, win[2], u);
@@ -378,29 +374,58 @@ k_cells(CellArgs a) {
             u = fmaf(kb.y, win[5], u);
             u = fmaf(kb.z, win[6], u);
             if (u * 1.00001f >= thr_lo) {  // the factor covers the rounding of the chains on both sides
-                const int entry = (plane << 14) | (y << 7) | x;
-                if (regL[y] & regx)
-                    list[atomicAdd(&s_nr, 1)] = entry;
+                if (a.regy[y] & regx)
+                    m_reg |= 1u << (y - ya);
                 else
-                    list[hc * wc - 1 - atomicAdd(&s_ne, 1)] = entry;
+                    m_edge |= 1u << (y - ya);
             }
-#pragma unroll
-            for (int p = 0; p < 6; ++p) win[p] = win[p + 1];
-            win[6] = V[(size_t)pd_clampi(y + 4, 0, h - 1) * wc + x];
         }
     }
-    __syncthreads();
-    const int nr = s_nr, ne = s_ne;
-    const int seg = plane % KF_NSEG;
-    if (tid == 0) {
-        s_br = nr ? atomicAdd(a.n_reg + seg, nr) : 0;
-        s_be = ne ? atomicAdd(a.n_edge + seg, ne) : 0;
+    // ---- list space: counts per wavefront, one reservation per workgroup and kind
+    const int c_r = __builtin_popcount(m_reg), c_e = __builtin_popcount(m_edge);
+    int p_r = c_r, p_e = c_e;  // inclusive prefix over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o_r = __shfl_up(p_r, d), o_e = __shfl_up(p_e, d);
+        if (lane >= d) {
+            p_r += o_r;
+            p_e += o_e;
+        }
+    }
+    if (lane == 63) {
+        s_cnt[wv][0] = p_r;
+        s_cnt[wv][1] = p_e;
     }
     __syncthreads();
-    // every cell is listed at most once and a segment has room for all cells of its planes
+    const int seg = plane % KF_NSEG;
+    if (tid == 0) {
+        int nr = 0, ne = 0;
+        for (int q = 0; q < n_waves; ++q) {
+            nr += s_cnt[q][0];
+            ne += s_cnt[q][1];
+        }
+        s_base[0] = nr ? atomicAdd(a.n_reg + seg, nr) : 0;
+        s_base[1] = ne ? atomicAdd(a.n_edge + seg, ne) : 0;
+    }
+    __syncthreads();
+    int at_r = s_base[0] + p_r - c_r, at_e = s_base[1] + p_e - c_e;
+    for (int q = 0; q < wv; ++q) {
+        at_r += s_cnt[q][0];
+        at_e += s_cnt[q][1];
+    }
+    // every cell is listed at most once and a segment has room for all cells of its planes:
+    // interior-weight cells from the front of the segment, the others from its back
     int32_t* segment = a.cells + (size_t)seg * a.seg_cap;
-    for (int i = tid; i < nr; i += NT) segment[s_br + i] = list[i];
-    for (int i = tid; i < ne; i += NT) segment[a.seg_cap - 1 - (s_be + i)] = list[hc * wc - 1 - i];
+    while (m_reg) {
+        const int bit = __builtin_ctz(m_reg);
+        m_reg &= m_reg - 1u;
+        segment[at_r++] = (plane << 14) | ((ya + bit) << 7) | x;
+    }
+    while (m_edge) {
+        const int bit = __builtin_ctz(m_edge);
+        m_edge &= m_edge - 1u;
+        segment[a.seg_cap - 1 - (at_e++)] = (plane << 14) | ((ya + bit) << 7) | x;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -899,9 +924,13 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         pd_prof_end(ctx);
     }
     static const int cells_nt = getenv("PD_CELLS_THREADS") ? atoi(getenv("PD_CELLS_THREADS")) : 0;  // comparison runs
+    const int nt_cells = cells_nt > 0 ? cells_nt : (gather ? 256 : 512);
+    const int bands = nt_cells / wc;
+    const int rows_per = bands ? (hc + bands - 1) / bands : 64;
+    const size_t cells_lds = sizeof(float) * (size_t)h * w;
+    if (nt_cells % 64 || nt_cells > 512 || rows_per > 32 || hc > h || wc > w || cells_lds > 60 * 1024) return PD_E_STATE;  // (a bit per row of a band)
     pd_prof_begin(ctx, PD_STAGE_CELLS);
-    hipLaunchKernelGGL(k_cells, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(cells_nt > 0 ? cells_nt : (gather ? 256 : 512)),
-                       sizeof(float) * ((size_t)h * w + (size_t)h * wc + 9 * (size_t)(hc + wc)), ctx->stream, c);
+    hipLaunchKernelGGL(k_cells, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(nt_cells), cells_lds, ctx->stream, c);
     pd_prof_end(ctx);
     // the list lengths are only known on the device: fixed grids stride over them
     size_t fblocks = (n_cells_max / 8 + KF_CELLS_PER_BLOCK - 1) / KF_CELLS_PER_BLOCK;
