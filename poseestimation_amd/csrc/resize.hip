@@ -436,8 +436,15 @@ k_resize_tiles(AvgArgs a, int groups_per_block) {
     const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;   // tiles that share source rows share an XCD
     if (tile >= tiles) return;
     const int X0 = (tile % tiles_x) * FT_TW, Y0 = (tile / tiles_x) * FT_TH;
-    const bool inside = X0 + (tid % FT_TW) < a.W && Y0 + (tid / FT_TW) < a.H;
-    const int X = min(X0 + (tid % FT_TW), a.W - 1), Y = min(Y0 + (tid / FT_TW), a.H - 1);
+    // Output pixel of a thread: a wavefront owns four rows of the tile, and the sixteen lanes that
+    // a 16-byte LDS read serves in one cycle (lanes 0-3, 12-15, 20-27 | 4-11, 16-19, 28-31 of each
+    // half) own one row, so that the taps of stage C fall on consecutive patch pixels of one row.
+    const int l5 = tid & 31;
+    const bool first = l5 < 4 || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
+    const int px = first ? (l5 < 4 ? l5 : l5 < 16 ? l5 - 8 : l5 - 12) : (l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 - 16);
+    const int py = (tid >> 6) * 4 + ((tid >> 5) & 1) * 2 + (first ? 0 : 1);
+    const bool inside = X0 + px < a.W && Y0 + py < a.H;
+    const int X = min(X0 + px, a.W - 1), Y = min(Y0 + py, a.H - 1);
     const int Ylast = min(Y0 + FT_TH - 1, a.H - 1), Xlast = min(X0 + FT_TW - 1, a.W - 1);
     const int b = blockIdx.z;
     const int n_groups = (a.C + FT_CH - 1) / FT_CH;
