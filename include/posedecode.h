@@ -184,7 +184,7 @@ enum {
     PD_STAGE_SORT = 2,       /* peak ordering and id assignment, where it is a kernel of its own */
     PD_STAGE_PAIRS = 3,      /* PAF line integrals */
     PD_STAGE_MATCH = 4,      /* per-limb sort + greedy matching */
-    PD_STAGE_PARSE = 5,      /* person assembly */
+    PD_STAGE_PARSE = 5,      /* person assembly (pd_decode_batch into the library's own buffer: assembly and packing share a launch, timed here) */
     PD_STAGE_PACK = 6,       /* result packing */
     PD_STAGE_FILTER = 7,     /* float32 candidate filter (active cells, or every pixel of full-resolution maps) */
     PD_STAGE_VERIFY = 8,     /* exact float64 verification of the candidates */

@@ -103,8 +103,9 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     CR(dev_alloc(ctx, (void**)&ctx->raw, B * PD_N_PARTS * PK * sizeof(RawPeak)));
     // counters that start every decode at zero share one allocation and one memset
     ctx->zero_bytes = (2 * B * PD_N_PARTS + 96) * sizeof(int32_t);
-    CR(dev_alloc(ctx, (void**)&ctx->zero_block, ctx->zero_bytes));
-    CRH(hipMemset(ctx->zero_block, 0, ctx->zero_bytes));
+    CR(dev_alloc(ctx, (void**)&ctx->zero_block, ctx->zero_bytes + 64));  // + the arrival counter of the pack
+    CRH(hipMemset(ctx->zero_block, 0, ctx->zero_bytes + 64));
+    ctx->pack_ticket = ctx->zero_block + ctx->zero_bytes / sizeof(int32_t);
     ctx->zero_clean = 1;
     CR(dev_alloc(ctx, (void**)&ctx->full_absmax, B * sizeof(float)));
     CR(dev_alloc(ctx, (void**)&ctx->plane_slack, B * PD_N_PARTS * sizeof(float2)));
@@ -666,12 +667,19 @@ extern "C" int pd_debug_found(pd_ctx* ctx, int enable, int32_t* out) {
     return PD_OK;
 }
 
+static int after_pack(pd_ctx* ctx);
+
 extern "C" int pd_pack(pd_ctx* ctx) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     if (!ctx->have_peaks && !ctx->have_conns && !ctx->have_persons) PD_FAIL(ctx, PD_E_STATE, "pd_pack: nothing to pack");
     int rc = pd_launch_pack(ctx);
     if (rc != PD_OK) return rc;
+    return after_pack(ctx);
+}
+
+// Host side of a queued pack: what of the results is (or will be) in the host mirror.
+static int after_pack(pd_ctx* ctx) {
     if (skeleton_only(ctx)) {  // nothing for pd_fetch and its like: they report PD_E_STATE
         ctx->res_have = 0;
         ctx->packed = 0;
@@ -740,6 +748,11 @@ extern "C" int pd_decode_fullres(pd_ctx* ctx, double thre1, double thre2) {
     if (rc != PD_OK) return rc;
     rc = pd_connections(ctx, thre2);
     if (rc != PD_OK) return rc;
+    if (pd_parse_pack_fused(ctx)) {
+        rc = pd_launch_parse_pack(ctx);
+        if (rc != PD_OK) return rc;
+        return after_pack(ctx);
+    }
     rc = pd_parse(ctx);
     if (rc != PD_OK) return rc;
     return pd_pack(ctx);

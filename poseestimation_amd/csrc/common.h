@@ -185,6 +185,7 @@ struct pd_ctx {
     int32_t* zero_block; // raw_count | cand_count + list counters: zero at the start of every decode
     size_t zero_bytes;
     int zero_clean;      // the block is zero (or a kernel that zeroes it is queued): pd_pack leaves it so
+    int32_t* pack_ticket; // behind the block: arrival counter of k_parse_pack, zero between launches (NULL: not available)
     int64_t* fstats;     // what pd_filter_stats reports, summed up by k_sort_peaks before the counters go
     RawPeak* raw;        // [B][18][PK] unordered
     int32_t* raw_count;  // [B][18]
@@ -336,6 +337,8 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2);
 int pd_launch_match(pd_ctx* ctx);
 int pd_launch_parse(pd_ctx* ctx);
 int pd_launch_pack(pd_ctx* ctx);
+bool pd_parse_pack_fused(const pd_ctx* ctx);
+int pd_launch_parse_pack(pd_ctx* ctx);  // person assembly + packing in one launch
 int pd_launch_hwc_to_planar(pd_ctx* ctx, const void* src, int dtype, int Csrc, int Cdst, int B, int H,
                             int W, double* dst, float* absmax);
 int pd_launch_planar_to_hwc(pd_ctx* ctx, const double* src, int C, int B, int H, int W, double* dst);

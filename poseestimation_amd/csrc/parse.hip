@@ -22,7 +22,18 @@ struct ParseArgs {
     int32_t* dbg_found;  // [B][PK] or NULL: len(found) of every limb-18 connection (utils/postprocess.py:224-225)
 };
 
-// The table form for image b; tab holds max_persons rows of 20 doubles in LDS.
+// What the assembly leaves in memory (person rows, counts, status) is stored write-through at
+// agent scope: k_parse_pack hands it to another workgroup inside the launch, and such stores
+// need no cache write-back before the hand-over.
+__device__ __forceinline__ void put_out(double* p, double v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void put_out(int32_t* p, int32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The table form for image b; tab holds max_persons rows of 20 doubles in LDS.  Run by one
+// wavefront (its lanes are ordered among themselves with pd_wave_sync).
 __device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
     int n = 0;           // live rows
     int err = PD_OK;
@@ -84,7 +95,7 @@ __device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
                     }
                     if (lane == 18) tab[j0 * 20 + 18] = (tab[j0 * 20 + 18] + tab[j1 * 20 + 18]) + r.score;
                     if (lane == 19) tab[j0 * 20 + 19] = tab[j0 * 20 + 19] + tab[j1 * 20 + 19];
-                    __syncthreads();
+                    pd_wave_sync();
                     if (lane < 20)
                         for (int j = j1; j < n - 1; ++j) tab[j * 20 + lane] = tab[(j + 1) * 20 + lane];
                     --n;
@@ -96,7 +107,7 @@ __device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
             } else if (a.mode == PD_MODE_D) {
                 err = PD_E_INDEX;  // predict.py:199 subset_idx[found] with found == 2
             }
-            __syncthreads();
+            pd_wave_sync();
             if (err == PD_E_INDEX) break;
         }
         if (err == PD_E_INDEX) break;
@@ -114,13 +125,13 @@ __device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
         const unsigned long long m = __ballot(keep);
         if (keep) {
             const int pos = kept + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            for (int c = 0; c < 20; ++c) out[(size_t)pos * 20 + c] = tab[j * 20 + c];
+            for (int c = 0; c < 20; ++c) put_out(out + (size_t)pos * 20 + c, tab[j * 20 + c]);
         }
         kept += __builtin_popcountll(m);
     }
     if (lane == 0) {
-        a.person_count[b] = err == PD_E_INDEX ? 0 : kept;
-        if (err != PD_OK && a.status[b] == PD_OK) a.status[b] = err;
+        put_out(a.person_count + b, err == PD_E_INDEX ? 0 : kept);
+        if (err != PD_OK && a.status[b] == PD_OK) put_out(a.status + b, err);
     }
 }
 
@@ -420,12 +431,11 @@ __device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int 
     st.rc = rc;
 }
 
-// Prune and write out, or hand the image over.  No other wavefront of the workgroup may
-// still be running when this is called (the table form uses workgroup barriers).
+// Prune and write out, or hand the image over.
 __device__ __forceinline__ void wave_parse_end(const ParseArgs& a, int b, int lane, WaveShared& sh, WaveState& st) {
     if (st.rc == 1) {  // more connections or open persons than the wavefront form holds: the table form redoes this image
         if (a.only_flagged) {
-            if (lane == 0) a.person_count[b] = -1;
+            if (lane == 0) put_out(a.person_count + b, -1);
         } else {
             pd_wave_sync();
             parse_table(a, b, lane, sh.c_all);
@@ -434,8 +444,8 @@ __device__ __forceinline__ void wave_parse_end(const ParseArgs& a, int b, int la
     }
     if (st.rc == 2) {
         if (lane == 0) {
-            a.person_count[b] = 0;
-            if (a.status[b] == PD_OK) a.status[b] = PD_E_INDEX;
+            put_out(a.person_count + b, 0);
+            if (a.status[b] == PD_OK) put_out(a.status + b, (int32_t)PD_E_INDEX);
         }
         return;
     }
@@ -446,11 +456,11 @@ __device__ __forceinline__ void wave_parse_end(const ParseArgs& a, int b, int la
     if (keep) {
         double* out = a.persons + ((size_t)b * a.max_persons + __builtin_popcountll(m & ((1ull << lane) - 1ull))) * 20;
 #pragma unroll
-        for (int p = 0; p < PD_N_PARTS; ++p) out[p] = (double)sh.ids[p][lane];
-        out[18] = st.my_score;
-        out[19] = (double)st.my_cnt;
+        for (int p = 0; p < PD_N_PARTS; ++p) put_out(out + p, (double)sh.ids[p][lane]);
+        put_out(out + 18, st.my_score);
+        put_out(out + 19, (double)st.my_cnt);
     }
-    if (lane == 0) a.person_count[b] = __builtin_popcountll(m);
+    if (lane == 0) put_out(a.person_count + b, (int32_t)__builtin_popcountll(m));
 }
 
 __global__ void __launch_bounds__(64)
@@ -600,6 +610,195 @@ k_pack(PackArgs a) {
 #undef PD_PUT
 }
 
+// ---- person assembly and packing in one launch ----------------------------------------
+// One workgroup of four wavefronts per image.  Wavefront 0 assembles the persons of the image
+// (the body of k_parse_wave); meanwhile the other three, each on its own, sum the peak and
+// connection counts of all images (which the earlier launches left complete) and copy this
+// image's count tables, peaks and connections to their places in the result buffer.  The
+// person rows can only be placed once every image's person count is known: each workgroup
+// stores its rows write-through at agent scope and draws a ticket; the workgroup that draws the
+// last one (agent-scope acquire) writes the person rows of all images, the person / status tables and
+// the header.  The ticket word is zero between launches (the last workgroup resets it).
+struct ParsePackArgs {
+    ParseArgs p;
+    PackArgs k;
+    int32_t* ticket;
+};
+
+static_assert(sizeof(pd_conn) == 24, "k_parse_pack copies a connection as three 8-byte words");
+#define PP_CHUNK 256  // images whose person rows are placed per round of the last workgroup
+
+__global__ void __launch_bounds__(256)
+k_parse_pack(ParsePackArgs a) {
+    __shared__ WaveShared sh;
+    __shared__ int s_pb[3][PD_N_PARTS + 1], s_lb[3][PD_N_LIMBS + 1];
+    __shared__ long long s_tot[2];
+    __shared__ int s_last;
+    __shared__ int s_off[PP_CHUNK + 1], s_wsum[4], s_bad[4];
+    const PackArgs& k = a.k;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // every stage that reads the per-decode counters has run: leave them zero for the next decode
+    if (k.zero)
+        for (int i = b * 256 + tid; i < k.zero_words; i += gridDim.x * 256) k.zero[i] = 0;
+    const long long mirror = k.res2 ? k.res2 - k.res : 0;  // byte distance to the second copy
+#define PD_PUT(ptr, value)                                                \
+    do {                                                                  \
+        auto* p_ = (ptr);                                                 \
+        const auto v_ = (value);                                          \
+        *p_ = v_;                                                         \
+        if (k.res2) *(decltype(p_))((unsigned char*)p_ + mirror) = v_;    \
+    } while (0)
+    if (wv == 0) {
+        WaveState st;
+        wave_parse_begin(sh, st, lane);
+        wave_parse_limbs(a.p, b, lane, 0, PD_N_LIMBS, sh, st);
+        wave_parse_end(a.p, b, lane, sh, st);
+    } else {
+        const int w = wv - 1;
+        long long pre_p = 0, tot_p = 0, pre_c = 0, tot_c = 0;
+        for (int j = lane; j < k.B; j += 64) {
+            const long long np = k.part_base[j * (PD_N_PARTS + 1) + PD_N_PARTS];
+            tot_p += np;
+            if (j < b) pre_p += np;
+        }
+        for (int e = lane; e < k.B * PD_N_LIMBS; e += 64) {
+            const long long nc = max(0, k.limb_count[e]);
+            tot_c += nc;
+            if (e / PD_N_LIMBS < b) pre_c += nc;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            pre_p += __shfl_xor(pre_p, d);
+            tot_p += __shfl_xor(tot_p, d);
+            pre_c += __shfl_xor(pre_c, d);
+            tot_c += __shfl_xor(tot_c, d);
+        }
+        // where the parts / limbs of this image start in its runs of peaks / connections
+        if (lane <= PD_N_PARTS) s_pb[w][lane] = k.part_base[b * (PD_N_PARTS + 1) + lane];
+        const int my_nc = lane < PD_N_LIMBS ? max(0, k.limb_count[b * PD_N_LIMBS + lane]) : 0;
+        int incl = my_nc;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane < PD_N_LIMBS) s_lb[w][lane + 1] = incl;
+        if (lane == 0) s_lb[w][0] = 0;
+        pd_wave_sync();
+        if (w == 0) {
+            if (lane < PD_N_PARTS) PD_PUT((int32_t*)(k.res + k.lay.off_part) + b * PD_N_PARTS + lane, k.part_count[b * PD_N_PARTS + lane]);
+            if (lane < PD_N_LIMBS) PD_PUT((int32_t*)(k.res + k.lay.off_limb) + b * PD_N_LIMBS + lane, k.limb_count[b * PD_N_LIMBS + lane]);
+            if (lane == 0) {
+                s_tot[0] = tot_p;
+                s_tot[1] = tot_c;
+            }
+        }
+        pd_peak* out_peaks = (pd_peak*)(k.res + k.lay.off_payload) + pre_p;
+        pd_conn* out_conns = (pd_conn*)(k.res + k.lay.off_payload + tot_p * sizeof(pd_peak)) + pre_c;
+        const int n_p = s_pb[w][PD_N_PARTS], n_c = s_lb[w][PD_N_LIMBS];
+        for (int i = w * 64 + lane; i < n_p; i += 192) {
+            int p = 0;
+            while (i >= s_pb[w][p + 1]) ++p;
+            const size_t o = ((size_t)b * PD_N_PARTS + p) * k.PK + (i - s_pb[w][p]);
+            pd_peak q;
+            q.y = k.pk_y[o];
+            q.x = k.pk_x[o];
+            q.score = k.pk_score[o];
+            PD_PUT(out_peaks + i, q);
+        }
+        for (int i = w * 64 + lane; i < n_c; i += 192) {
+            int l = 0;
+            while (i >= s_lb[w][l + 1]) ++l;
+            // (three 8-byte words: a 24-byte struct copy goes through the stack)
+            const unsigned long long* src = (const unsigned long long*)(k.conn + ((size_t)b * PD_N_LIMBS + l) * k.PK + (i - s_lb[w][l]));
+            unsigned long long* dst = (unsigned long long*)(out_conns + i);
+            const unsigned long long c0 = src[0], c1 = src[1], c2 = src[2];
+            PD_PUT(dst, c0);
+            PD_PUT(dst + 1, c1);
+            PD_PUT(dst + 2, c2);
+        }
+    }
+    // this image's person rows, count and status were stored write-through and have arrived (the
+    // wait below, in every wavefront, then the barrier); the last workgroup to get here goes on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const long long n_peaks = s_tot[0], n_conns = s_tot[1];
+    double* out_persons = (double*)(k.res + k.lay.off_payload + n_peaks * sizeof(pd_peak) + n_conns * sizeof(pd_conn));
+    long long rows_before = 0;  // person rows of the images of earlier rounds
+    int bad = 0x7fffffff;
+    for (int j0 = 0; j0 < k.B; j0 += PP_CHUNK) {
+        const int j = j0 + tid;
+        int c = 0;
+        if (j < k.B) {
+            c = k.person_count[j];
+            const int stj = k.status[j];
+            PD_PUT((int32_t*)(k.res + k.lay.off_pers) + j, c);
+            PD_PUT((int32_t*)(k.res + k.lay.off_stat) + j, stj);
+            if (stj != PD_OK) bad = min(bad, j);
+        }
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int q = 0; q < wv; ++q) wbase += s_wsum[q];
+        s_off[tid] = wbase + incl - c;
+        const int rows = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        if (tid == 0) s_off[PP_CHUNK] = rows;
+        __syncthreads();
+        for (int r = tid; r < rows; r += 256) {
+            int lo = 0, hi = PP_CHUNK;  // last image of the round whose first row is <= r
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_off[mid] <= r)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const double* src = k.persons + ((size_t)(j0 + lo) * k.max_persons + (r - s_off[lo])) * 20;
+            double* dst = out_persons + (rows_before + r) * 20;
+            double v[20];
+#pragma unroll
+            for (int q = 0; q < 20; ++q) v[q] = src[q];
+#pragma unroll
+            for (int q = 0; q < 20; ++q) PD_PUT(dst + q, v[q]);
+        }
+        rows_before += rows;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bad = min(bad, __shfl_xor(bad, d));
+    if (lane == 0) s_bad[wv] = bad;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t* head = (int64_t*)k.res;
+        const int fb = min(min(s_bad[0], s_bad[1]), min(s_bad[2], s_bad[3]));
+        PD_PUT(head + 0, (int64_t)k.B);
+        PD_PUT(head + 1, (int64_t)n_peaks);
+        PD_PUT(head + 2, (int64_t)n_conns);
+        PD_PUT(head + 3, (int64_t)rows_before);
+        PD_PUT(head + 4, (int64_t)(fb == 0x7fffffff ? -1 : fb));
+        PD_PUT(head + 5, (int64_t)0);  // the library's own buffer holds any result by construction
+        __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#undef PD_PUT
+}
+
 int pd_launch_parse(pd_ctx* ctx) {
     ParseArgs a;
     a.mode = ctx->mode;
@@ -629,8 +828,7 @@ int pd_launch_parse(pd_ctx* ctx) {
     return PD_OK;
 }
 
-int pd_launch_pack(pd_ctx* ctx) {
-    PackArgs a;
+static void fill_pack_args(pd_ctx* ctx, PackArgs& a) {
     a.B = ctx->B;
     a.PK = ctx->cfg.max_peaks_per_part;
     a.max_persons = ctx->cfg.max_persons;
@@ -653,6 +851,49 @@ int pd_launch_pack(pd_ctx* ctx) {
     a.lay = pd_res_layout(ctx->B);
     a.zero = ctx->zero_block;
     a.zero_words = (int)(ctx->zero_bytes / sizeof(int32_t));
+}
+
+// Whether person assembly and packing of the current decode can share a launch: the library's
+// own result buffer (no capacity to check before anything is written), no skeleton buffer, the
+// wavefront form of the assembly with its hand-over inside the kernel.  PD_SEPARATE_PACK=1 in
+// the environment keeps the two launches (comparison runs).
+bool pd_parse_pack_fused(const pd_ctx* ctx) {
+    static const bool separate = [] {
+        const char* v = getenv("PD_SEPARATE_PACK");
+        return v && *v && *v != '0';
+    }();
+    return !separate && ctx->pack_ticket && ctx->impl != PD_IMPL_SIMPLE && !ctx->dbg_found && !ctx->skel_dst &&
+           ctx->host_results && ctx->res_user_cap == 0 && ctx->have_peaks && ctx->have_conns &&
+           (size_t)ctx->cfg.max_persons * 20 <= (size_t)WAVE_CONNS * 4;
+}
+
+int pd_launch_parse_pack(pd_ctx* ctx) {
+    ParsePackArgs a;
+    a.p.mode = ctx->mode;
+    a.p.PK = ctx->cfg.max_peaks_per_part;
+    a.p.max_persons = ctx->cfg.max_persons;
+    a.p.conn = ctx->conn;
+    a.p.conn_conf = ctx->conn_conf;
+    a.p.limb_count = ctx->limb_count;
+    a.p.persons = ctx->persons;
+    a.p.person_count = ctx->person_count;
+    a.p.status = ctx->status;
+    a.p.only_flagged = 0;
+    a.p.dbg_found = nullptr;
+    ctx->have_persons = 1;
+    fill_pack_args(ctx, a.k);
+    a.ticket = ctx->pack_ticket;
+    pd_prof_begin(ctx, PD_STAGE_PARSE);
+    hipLaunchKernelGGL(k_parse_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
+    pd_prof_end(ctx);
+    PD_HIP(ctx, hipGetLastError());
+    ctx->zero_clean = 1;
+    return PD_OK;
+}
+
+int pd_launch_pack(pd_ctx* ctx) {
+    PackArgs a;
+    fill_pack_args(ctx, a);
     pd_prof_begin(ctx, PD_STAGE_PACK);
     if (!ctx->skel_dst || ctx->host_results) {
         hipLaunchKernelGGL(k_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);

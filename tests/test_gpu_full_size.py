@@ -248,3 +248,51 @@ def test_config5_1024_images_streamed_in_chunks():
             np.testing.assert_array_equal(r.subset(256 * rr + i)[:, 18:], r.subset((i + 37 * rr) % 256)[:, 18:])
     for e in engs:
         e.close()
+
+
+def test_batch_beyond_one_round_of_person_placement():
+    """Person assembly and packing share a launch whose last workgroup places the person rows of
+    all images, 256 images per round: 600 small images (some empty) in one call against the same
+    images decoded in batches of 100, and a sample against the oracle."""
+    from poseestimation_amd import synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 96
+    B = 600
+    heat, paf = synth.batch(B, H, W, (0, 3), seed0=7000, paf_order='xy')
+    eng = DecodeEngine(max_batch=B, max_h=H, max_w=W, mode='D', max_peaks_per_part=32, max_persons=32,
+                       max_pairs_per_image=2000)
+    res = eng.decode_batch(heat, paf)
+    small = DecodeEngine(max_batch=100, max_h=H, max_w=W, mode='D', max_peaks_per_part=32, max_persons=32,
+                         max_pairs_per_image=2000)
+    n_persons = 0
+    for b0 in range(0, B, 100):
+        part = small.decode_batch(heat[b0:b0 + 100], paf[b0:b0 + 100])
+        for i in range(100):
+            gio.assert_peaks_equal(res.all_peaks(b0 + i), part.all_peaks(i), exact_score=True)
+            np.testing.assert_array_equal(res.subset(b0 + i), part.subset(i))
+            n_persons += len(part.subset(i))
+    assert n_persons > 300 and len(res.packed['persons']) == n_persons
+    for b in (0, 255, 256, 257, 511, 512, 599):
+        _assert_image(res, b, _oracle_image(heat[b], paf[b], 'D', H, W), 'D')
+    eng.close()
+    small.close()
+
+
+def test_more_than_64_open_persons_inside_the_fused_decode():
+    """An image with more open persons than the one-lane-per-person form holds is handed to the
+    table form inside the same launch (one wavefront of the image's workgroup runs it)."""
+    from poseestimation_amd import synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 656
+    heat = np.empty((2, H // 8, W // 8, 19), np.float32)
+    paf = np.empty((2, H // 8, W // 8, 38), np.float32)
+    heat[0], paf[0] = synth.scene(H, W, 90, 901, paf_order='xy')
+    heat[1], paf[1] = synth.scene(H, W, 5, 902, paf_order='xy')
+    eng = DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='D', max_peaks_per_part=128, max_persons=200,
+                       max_pairs_per_image=200000)
+    res = eng.decode_batch(heat, paf)
+    want = _oracle_image(heat[0], paf[0], 'D', H, W)
+    assert len(want[3]) > 64
+    for b in range(2):
+        _assert_image(res, b, _oracle_image(heat[b], paf[b], 'D', H, W), 'D')
+    eng.close()

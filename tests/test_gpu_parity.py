@@ -304,7 +304,8 @@ def test_device_resident_replay_follows_the_data(pdec, profile):
             assert np.array_equal(got[key], want[it % 2][key]), (it, key)
     if profile:
         prof = eng.ctx.profile_read()
-        assert prof['filter'][1] == 6 and prof['filter'][0] > 0 and prof['pack'][1] == 6
+        # (person assembly and packing share a launch on this path: it is timed as 'parse')
+        assert prof['filter'][1] == 6 and prof['filter'][0] > 0 and prof['parse'][1] == 6 and prof['pack'][1] in (0, 6)
     eng.close()
 
 
