@@ -1,5 +1,5 @@
-"""Per hardware queue: how long a decode's kernel chain takes (first kernel's start to the pack
-kernel's end) and how long the queue then sits idle before the next chain starts.
+"""Per hardware queue: how long a decode's kernel chain takes (first kernel's start to the end of
+the packing kernel) and how long the queue then sits idle before the next chain starts.
 Usage: chain_gaps.py <kernel_trace.csv> [first_chain [last_chain]] (chains counted per queue)."""
 import collections
 import csv
@@ -19,7 +19,7 @@ for q, v in sorted(byq.items()):
     chains, cur = [], []
     for k in v:
         cur.append(k)
-        if k[2].endswith('k_pack'):
+        if k[2].endswith('k_pack') or k[2].endswith('k_parse_pack'):
             chains.append(cur)
             cur = []
     chains = chains[lo:hi]

@@ -41,8 +41,8 @@ shutil.copy(newest(os.path.join(SRC, 'trace', '*', '*kernel_stats.csv')),
 shutil.copy(os.path.join(SRC, 'bench.json'), os.path.join(DST, '%s_%s_bench.json' % (tag, workload)))
 shutil.copy(os.path.join(SRC, 'trace_bench.json'), os.path.join(DST, '%s_%s_bench_under_rocprof.json' % (tag, workload)))
 fetch, write = counters('fetch'), counters('write')
-# every decode ends with one k_pack launch
-decodes = max([n for k, (v, n) in list(fetch.items()) + list(write.items()) if k.startswith('k_pack')] + [1])
+# every decode ends with one packing launch (k_parse_pack, or k_pack where assembly and packing are apart)
+decodes = max([n for k, (v, n) in list(fetch.items()) + list(write.items()) if k.startswith('k_pack') or k.startswith('k_parse_pack')] + [1])
 out = {'workload': workload, 'unit': 'bytes per launch', 'build': tag,
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of "bench.py --workload %s --no-cpu '
                  '--no-extras --steps 6 --warmup 2 --contexts 1"; mean over the launches of a kernel; counters are in '
