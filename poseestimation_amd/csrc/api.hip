@@ -74,6 +74,8 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     // PD_PACK_COPY=1: always a device-to-host copy behind the pack; PD_PACK_DIRECT=1: never
     ctx->pack_policy = getenv("PD_PACK_COPY") ? 0 : (getenv("PD_PACK_DIRECT") ? 1 : -1);
     ctx->pack_direct = ctx->pack_policy != 0;
+    ctx->last_peaks_per_image = -1;
+    ctx->pairs_pre = 1;
 #define CR(call)                                                                     \
     do {                                                                             \
         int rc_ = (call);                                                            \
@@ -740,7 +742,24 @@ static int finish_results(pd_ctx* ctx) {
     }
     if (ctx->pack_direct) ctx->res_have = end;  // what pd_results_host reports: the bytes in use
     ctx->last_result_bytes = end;
+    ctx->last_peaks_per_image = ctx->B > 0 ? (long long)head[1] / ctx->B : -1;
     return PD_OK;
+}
+
+// More than about 160 peaks per image means more candidate pairs than the direct form of the
+// pair kernel takes in two passes (19 limbs x (peaks / 18)^2 > 1536).  PD_PAIRS_PRE=0/1 in the
+// environment fixes the choice (comparison runs).
+static void choose_pairs_kernel(pd_ctx* ctx) {
+    static const int forced = [] {
+        const char* v = getenv("PD_PAIRS_PRE");
+        return v && *v ? atoi(v) : -1;
+    }();
+    if (forced >= 0)
+        ctx->pairs_pre = forced != 0;
+    else if (ctx->last_peaks_per_image >= 0)
+        ctx->pairs_pre = ctx->last_peaks_per_image > 160;
+    else
+        ctx->pairs_pre = (long long)ctx->H * ctx->W > 512LL * 512LL;
 }
 
 extern "C" int pd_decode_fullres(pd_ctx* ctx, double thre1, double thre2) {
@@ -766,6 +785,7 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     if (rc != PD_OK) return rc;
     if (mem != PD_MEM_DEVICE || !ctx->use_graph) {
         if (ctx->pack_policy < 0) ctx->pack_direct = ctx->last_result_bytes <= PD_PACK_DIRECT_LIMIT;
+    choose_pairs_kernel(ctx);
         return pd_decode_fullres(ctx, thre1, thre2);
     }
 
@@ -774,9 +794,11 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     // HIP graph the second time the same call is seen and replayed from then on, which
     // takes the per-launch host cost out of the steady state.
     if (ctx->pack_policy < 0) ctx->pack_direct = ctx->last_result_bytes <= PD_PACK_DIRECT_LIMIT;
+    choose_pairs_kernel(ctx);
     GraphKey key;
     memset(&key, 0, sizeof(key));
     key.pack_direct = ctx->pack_direct;
+    key.pairs_pre = ctx->pairs_pre;
     key.heat = heat;
     key.paf = paf;
     key.B = B;

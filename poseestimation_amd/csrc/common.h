@@ -96,6 +96,7 @@ struct GraphKey {
     uint32_t prof;
     int host_results;
     int pack_direct;
+    int pairs_pre;
     const void* skel;
     uint64_t skel_cap;
     uint64_t gen;  // pd_ctx::gen at the time: any device buffer or table a launch refers to that was
@@ -217,6 +218,11 @@ struct pd_ctx {
     // results, 0 always copy, 1 always direct; pack_direct: what the next pack does.
     int pack_policy, pack_direct;
     size_t last_result_bytes;
+    // Pair scoring with or without its pre-test (the pre-test pays when images hold many peaks; the
+    // kernel without it is leaner): by the peaks per image of the last fetched results, before any
+    // by the size of the map.  Same results either way.
+    int pairs_pre;
+    long long last_peaks_per_image;  // -1: no results fetched yet
     int have_peaks, have_conns, have_persons, packed;
     unsigned char* skel_dst;  // caller's device buffer for the skeleton copy of the results (or NULL)
     size_t skel_cap;

@@ -105,7 +105,7 @@ struct PairGeo {
     double prior;    // min(0.5 * H / norm - 1, 0)
     int ya, xa, yb, xb;
     int k;           // limb, or -1: the pair is skipped (coincident peaks in mode P) or absent
-    int pad;
+    int pad;         // pre-test: samples found at or under the threshold so far
 };
 
 #define PAIRS_PER_CHUNK 6   // pairs a wavefront takes at a time: 6 lanes x 1 pair, then 6 pairs x 10 samples
@@ -232,16 +232,21 @@ __device__ __forceinline__ void score_six(const PairArgs& a, int b, int lane, co
 // chunks are scored directly.  Images with many: most candidates join unrelated peaks
 // and fail at any sample between them, and a pair with two samples at or under the
 // threshold is rejected whatever the others say -- so one lane per pair first takes
-// samples 4 and 5, and only the pairs that pass at least one of them are scored in full.
+// samples 4 and 5, one lane per survivor then samples 2 and 7, and only the pairs with at
+// most one of the four at or under the threshold are scored in full.
 // The grid is one-dimensional and swizzled so that the workgroups of one image run on
 // one XCD (workgroup i goes to XCD i % 8) and its PAF map stays in that XCD's L2.
+// PRE = false: the kernel without the pre-test (every image takes the direct form, whatever its
+// number of pairs: same results), a fifth of the LDS and fewer registers; the host picks it for
+// decodes whose images hold few peaks.
+template <bool PRE>
 __global__ void __launch_bounds__(256)
 k_pair_scores(PairArgs a) {
     __shared__ int32_t s_off[PD_N_LIMBS + 1];
     __shared__ int32_t s_cnt[PD_N_PARTS];
     __shared__ float4 s_up[8];
-    __shared__ PairGeo s_geo[4][PRE_PAIRS];  // a wavefront's staged pairs: six at a time, or the pre-test's survivors
-    __shared__ int s_p[4][PRE_PAIRS];
+    __shared__ PairGeo s_geo[4][PRE ? PRE_PAIRS : 8];  // a wavefront's staged pairs: six at a time, or the pre-test's survivors
+    __shared__ int s_p[4][PRE ? PRE_PAIRS : 8];
     __shared__ double s_mid[4][6][10];
     const int tid = threadIdx.x;
     const int per_xcd = gridDim.x / 8;  // the grid is a multiple of 8 workgroups
@@ -264,7 +269,7 @@ k_pair_scores(PairArgs a) {
     const int wave_id = blk * 4 + wv;
     PairGeo* geo = s_geo[wv];
     int* pq = s_p[wv];
-    if (total <= 2 * n_waves * PAIRS_PER_CHUNK) {
+    if (!PRE || total <= 2 * n_waves * PAIRS_PER_CHUNK) {
         for (int base = wave_id * PAIRS_PER_CHUNK; base < total; base += n_waves * PAIRS_PER_CHUNK) {
             if (lane < PAIRS_PER_CHUNK) {
                 PairGeo g;
@@ -280,23 +285,20 @@ k_pair_scores(PairArgs a) {
         return;
     }
     for (int base = wave_id * PRE_PAIRS; base < total; base += n_waves * PRE_PAIRS) {
+        // the geometry of this pass's pairs, one lane per pair, into the wavefront's list
         int nq = 0;
+#pragma unroll 1
         for (int r = 0; r < PRE_PAIRS / 64; ++r) {
             const int p = base + r * 64 + lane;
-            bool survives = false;
+            bool ok = false;
             PairGeo g;
             g.k = -1;
             if (p < total) {
-                if (!pair_geometry(a, b, p, s_off, s_cnt, g)) {
-                    a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
-                } else {
-                    const double m4 = pair_sample(a, b, g, 4, s_up), m5 = pair_sample(a, b, g, 5, s_up);
-                    survives = (m4 > a.thr) || (m5 > a.thr);
-                    if (!survives) a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
-                }
+                ok = pair_geometry(a, b, p, s_off, s_cnt, g);
+                if (!ok) a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
             }
-            const unsigned long long m = __ballot(survives);
-            if (survives) {
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
                 const int at = nq + __builtin_popcountll(m & ((1ull << lane) - 1ull));
                 geo[at] = g;
                 pq[at] = p;
@@ -304,6 +306,39 @@ k_pair_scores(PairArgs a) {
             nq += __builtin_popcountll(m);
         }
         pd_wave_sync();
+        // two rounds, one lane per listed pair: samples 4 and 5, then 2 and 7 of the survivors.
+        // A pair with two samples at or under the threshold is out; the list is compacted in
+        // place (a step writes only entries that it or an earlier step has read).
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            const int ia = round == 0 ? 4 : 2, ib = round == 0 ? 5 : 7;
+            int kept = 0;
+#pragma unroll 1
+            for (int q0 = 0; q0 < nq; q0 += 64) {
+                const int idx = q0 + lane;
+                bool survives = false;
+                PairGeo g;
+                int p = 0;
+                if (idx < nq) {
+                    g = geo[idx];
+                    p = pq[idx];
+                    const double ma = pair_sample(a, b, g, ia, s_up), mb = pair_sample(a, b, g, ib, s_up);
+                    g.pad += (ma > a.thr ? 0 : 1) + (mb > a.thr ? 0 : 1);  // samples at or under the threshold so far
+                    survives = g.pad < 2;
+                    if (!survives) a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
+                }
+                pd_wave_sync();
+                const unsigned long long m = __ballot(survives);
+                if (survives) {
+                    const int at = kept + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    geo[at] = g;
+                    pq[at] = p;
+                }
+                kept += __builtin_popcountll(m);
+                pd_wave_sync();
+            }
+            nq = kept;
+        }
         for (int q0 = 0; q0 < nq; q0 += PAIRS_PER_CHUNK)
             score_six(a, b, lane, s_up, geo + q0, pq + q0, min(PAIRS_PER_CHUNK, nq - q0), s_mid[wv]);
     }
@@ -375,7 +410,10 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     if (a.pairs)
         hipLaunchKernelGGL(k_paf_pairs, dim3((ctx->h * ctx->w + PP_PIX - 1) / PP_PIX, ctx->B), dim3(256), 0, ctx->stream,
                            ctx->lo_paf, ctx->h * ctx->w, ctx->paf_pairs);
-    hipLaunchKernelGGL(k_pair_scores, dim3(per_image * ctx->B), dim3(256), 0, ctx->stream, a);
+    if (ctx->pairs_pre)
+        hipLaunchKernelGGL(k_pair_scores<true>, dim3(per_image * ctx->B), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_pair_scores<false>, dim3(per_image * ctx->B), dim3(256), 0, ctx->stream, a);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return PD_OK;
