@@ -70,7 +70,7 @@ def main():
     ap.add_argument('--no-stage-timing', action='store_true',
                     help='experiments: no event pair around the roofline kernel in the timed region')
     ap.add_argument('--contexts', type=int, default=0,
-                    help='decode contexts (HIP streams) per GPU, used round-robin (0: 4; 1 for the multi-scale workload, whose kernels fill the chip by themselves)')
+                    help='decode contexts (HIP streams) per GPU, used round-robin (0: 4, 3 in the round pipeline; 1 for the multi-scale workload, whose kernels fill the chip by themselves)')
     ap.add_argument('--pipeline', default='', choices=['', 'fetch', 'rounds'],
                     help='N = 1 only.  fetch: every decode copies its full packed results (with the connection '
                          'lists) to the host; rounds: the N > 1 pipeline with a plain device-to-host copy in place of '
@@ -78,7 +78,7 @@ def main():
                          'launcher threads).  Default: fetch, rounds for the stream workload')
     ap.add_argument('--hw-queues', type=int, default=-1,
                     help='GPU_MAX_HW_QUEUES for this process when the environment asks for fewer '
-                         '(0: leave it; -1: 8 on one GPU with the fetch pipeline, left alone otherwise)')
+                         '(0: leave it; -1: 8, left alone for the multi-scale workload)')
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     if args.steps <= 0:
@@ -91,10 +91,13 @@ def main():
     if not args.pipeline:
         args.pipeline = 'rounds' if wl['per_step'] > 1 else 'fetch'
     rounds = (use_dist or args.pipeline == 'rounds') and not multiscale
+    # The chip serves four hardware queues at a time: the fetch pipeline runs four contexts, the
+    # round pipeline three next to the stream of its gather / copy (measured: rounds with four
+    # contexts 0.77 M images/s on four queues and 0.65 M on eight, with three on eight 1.0 M).
     if args.contexts <= 0:
-        args.contexts = 1 if multiscale else 4
+        args.contexts = 1 if multiscale else (3 if rounds else 4)
     if args.hw_queues < 0:
-        args.hw_queues = 0 if (rounds or multiscale) else 8
+        args.hw_queues = 0 if multiscale else 8
 
     # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default);
     # streams that share a queue run one behind the other.  Every decode context needs a
@@ -200,7 +203,12 @@ def run_single(env):
     n_ctx = args.contexts
     per_step = wl['per_step']
     if rounds:
-        NBUF = n_ctx * GATHER_DEPTH * (2 if per_step > 1 else 1)   # one buffer per slice of a round (or of two)
+        # one buffer per slice of a round; of two rounds where one round's inputs would fit the
+        # 256 MiB Infinity Cache (the inputs of a step must come from HBM, as a network's outputs would)
+        NBUF = n_ctx * GATHER_DEPTH
+        two_rounds = per_step > 1 or NBUF * B * h * w * 57 * 4 < (320 << 20)
+        if two_rounds:
+            NBUF *= 2
     else:
         NBUF = 12 if B * h * w * 57 * 4 < (64 << 20) else 4
         NBUF = graph_friendly_buffers(NBUF, n_ctx)
@@ -273,7 +281,7 @@ def run_single(env):
             bufs = []
             # the contexts' launcher threads issue the launches (or graph replays) in parallel
             for j in range(k):
-                kb = (s * n * GATHER_DEPTH + j) % NBUF if per_step > 1 else j % NBUF
+                kb = (s * n * GATHER_DEPTH + j) % NBUF if two_rounds else j % NBUF
                 bufs.append(kb)
                 pool[j % n].ctx.submit(d_heat[kb].data_ptr(), d_paf[kb].data_ptr(), B, h, w, H, W, 0.1, 0.05,
                                        g.slice_ptr(s, j), g.capacity)
