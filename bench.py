@@ -415,8 +415,8 @@ def run_single(env):
             allres = sharding.SkeletonGather.results(rows)
             res0, buf0 = allres[0], bufs[0]
         # Bytes one decode has to move for this algorithm: the network output read once, the
-        # packed results written once.  (The survey's per-image formula prices an implementation
-        # that materialises the x8 maps; this path never forms them -- see `dense_path`.)
+        # packed results written once.  (The per-image byte formula of a materialising pipeline -- x8 maps
+        # written and read back -- prices an implementation that forms them; this path never forms them -- see `dense_path`.)
         result_bytes = int(len(res0['raw'])) if 'raw' in res0 else int(res0['peaks'].nbytes + res0['persons'].nbytes)
         must_bytes = B * n * 57 * 4.0 + result_bytes
         decode_s = step_s / per_step
@@ -611,7 +611,7 @@ def run_multiscale(env):
         resize_ms = stage['resize'][0] / max(args.steps, 1)
         resize_launches = stage['resize'][1] / max(args.steps, 1)
         must = B * (228.0 * n_sum + 57.0 * N * 8)                          # network outputs read, float64 averages written
-        survey = B * (228.0 * n_sum + 2 * 228.0 * N_sum + 57.0 * N * 8)    # + the four x8 maps written and read back
+        materialised = B * (228.0 * n_sum + 2 * 228.0 * N_sum + 57.0 * N * 8)    # + the four x8 maps written and read back
         pmc = pmc_traffic(args.workload)
         traffic = pmc.get('resize_stage_hbm_bytes') if pmc else None
         roofline = {
@@ -625,13 +625,13 @@ def run_multiscale(env):
                              'averages written once',
             'avg_launch_ms': resize_ms,
             'measured': 'HIP event pairs around the stage\'s kernels in every step of the timed region',
-            'survey_formula_bytes': survey,
-            'survey_formula_note': 'the survey\'s per-image formula also counts the four x8 maps written and read back '
+            'materialising_formula_bytes': materialised,
+            'materialising_formula_note': 'the byte formula of a pipeline that materialises the x8 maps also counts them written and read back '
                                    '(2 * 228 * sum_s N_s); an implementation that materialises them moves that much',
         }
-        sf = survey / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        roofline['survey_formula_frac'] = sf if sf <= 1.0 else None
-        roofline['survey_formula_speedup_vs_hbm_peak'] = sf
+        sf = materialised / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roofline['materialising_formula_frac'] = sf if sf <= 1.0 else None
+        roofline['materialising_formula_speedup_vs_hbm_peak'] = sf
         if traffic:
             roofline['traffic_frac'] = traffic / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             roofline['wasted_traffic_ratio'] = traffic / must
