@@ -532,6 +532,10 @@ k_resize_tiles(AvgArgs a, int groups_per_block) {
     __syncthreads();
 
     float amax = 0.f;
+    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread's source pixel of the coming round
+    if (g_begin < g_end && th[0].o0 != ~0u)
+        pre = load_channels(a.s[0].lo + (size_t)b * a.s[0].hs * a.s[0].ws * a.C + g_begin * FT_CH + th[0].o0,
+                            min(FT_CH, a.C - g_begin * FT_CH));
     for (int g = g_begin; g < g_end; ++g) {
         const int ch0 = g * FT_CH;
         const int nch = min(FT_CH, a.C - ch0);
@@ -553,9 +557,18 @@ k_resize_tiles(AvgArgs a, int groups_per_block) {
             const ScaleSrc& sc = a.s[m];
             const TileScale& t = ts[m];
             const ThreadScale& q = th[m];
-            // 0: the source pixels the patch draws on
-            if (q.o0 != ~0u) srcp[tid] = load_channels(sc.lo + (size_t)b * sc.hs * sc.ws * a.C + ch0 + q.o0, nch);
+            // 0: the source pixels the patch draws on (requested a round ago)
+            if (q.o0 != ~0u) srcp[tid] = pre;
             __syncthreads();
+            // the next round's source pixel is requested now and arrives while this round computes
+            if (m + 1 < NS) {
+                if (th[m + 1].o0 != ~0u)
+                    pre = load_channels(a.s[m + 1].lo + (size_t)b * a.s[m + 1].hs * a.s[m + 1].ws * a.C + ch0 + th[m + 1].o0, nch);
+            } else if (g + 1 < g_end) {
+                if (th[0].o0 != ~0u)
+                    pre = load_channels(a.s[0].lo + (size_t)b * a.s[0].hs * a.s[0].ws * a.C + (ch0 + FT_CH) + th[0].o0,
+                                        min(FT_CH, a.C - (ch0 + FT_CH)));
+            }
             // A: horizontal sums
 #pragma unroll
             for (int k = 0; k < RT_AQ; ++k) {
