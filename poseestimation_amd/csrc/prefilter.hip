@@ -1014,18 +1014,25 @@ __device__ __forceinline__ void ff_emit(const FullFilterArgs& a, int plane, int 
         atomicOr(a.cand_count + plane, KF_OVERFLOW);  // no room: the exact kernel redoes the plane
 }
 
+#define FF_AHEAD 5  // rows on their way from memory per thread; divides the 25 unrolled row steps
+static_assert(25 % FF_AHEAD == 0 && PD_GR + FF_AHEAD < 2 * PD_GR + 2,
+              "a row's slot must be static, and a row requested ahead must reflect into the map (H >= 2 * PD_GR + 2)");
+struct FFRow {
+    double x, y;
+};
 struct FFState {
-    f2 s_prev1, s_prev2;  // smoothed rows y-1, y-2 of this thread's two columns
-    f2 pre0, pre1;        // map rows y+12, y+13 on their way from memory
+    f2 s_prev1, s_prev2;   // smoothed rows y-1, y-2 of this thread's two columns
+    FFRow pre[FF_AHEAD];   // map rows y+12 .. y+16 as loaded (converted when they enter the window,
+                           // so that nothing waits for them earlier); row r sits in slot r % FF_AHEAD
 };
 
-// Two adjacent map values of row r (reflected at the lower edge) as float32.
-__device__ __forceinline__ f2 ff_load_row(const double* __restrict__ col, int r, int H, int W, bool act1) {
+// Two adjacent map values of row r (reflected at the lower edge).
+__device__ __forceinline__ FFRow ff_load_row(const double* __restrict__ col, int r, int H, int W, bool act1) {
     if (r >= H) r = 2 * H - 1 - r;
     const double* p = col + (size_t)r * W;
-    f2 v;
-    v.x = (float)p[0];
-    v.y = act1 ? (float)p[1] : 0.f;
+    FFRow v;
+    v.x = p[0];
+    v.y = act1 ? p[1] : 0.0;
     return v;
 }
 
@@ -1038,10 +1045,16 @@ __device__ __forceinline__ void ff_row_step(const FullFilterArgs& a, const doubl
     float* yrow = ybuf + par * (FF_COLS + 2 * PD_GR + 2);
     const int li = c - xs;  // this thread's first column inside the strip
     if (y < H && act0) {
-        // row y + 12 was requested two steps ago; row y + 14 is requested now
-        win[(S + 12) % 25] = st.pre0;
-        st.pre0 = st.pre1;
-        st.pre1 = ff_load_row(col, y + PD_GR + 2, H, W, act1);
+        // row y + 12 was requested five steps ago; row y + 17 is requested now into its slot
+        // (12 % 5 == 17 % 5 and 25 % 5 == 0: the slot of a step is static)
+        {
+            const FFRow in = st.pre[(S + PD_GR) % FF_AHEAD];
+            f2 v;
+            v.x = (float)in.x;
+            v.y = (float)in.y;
+            win[(S + 12) % 25] = v;
+        }
+        st.pre[(S + PD_GR) % FF_AHEAD] = ff_load_row(col, y + PD_GR + FF_AHEAD, H, W, act1);
         f2 t = win[S] * c_gwf[12];
 #pragma unroll
         for (int d = 12; d >= 1; --d) t = __builtin_elementwise_fma(win[(S + 25 - d) % 25] + win[(S + d) % 25], (f2)(c_gwf[12 - d]), t);
@@ -1141,10 +1154,11 @@ k_full_filter(FullFilterArgs a) {
     FFState st;
     st.s_prev1 = (f2)(0.f);
     st.s_prev2 = (f2)(0.f);
-    st.pre0 = st.pre1 = (f2)(0.f);
-    if (act0) {
-        st.pre0 = ff_load_row(col, PD_GR, H, W, act1);
-        st.pre1 = ff_load_row(col, PD_GR + 1, H, W, act1);
+#pragma unroll
+    for (int i = 0; i < FF_AHEAD; ++i) {
+        st.pre[(PD_GR + i) % FF_AHEAD].x = 0.0;
+        st.pre[(PD_GR + i) % FF_AHEAD].y = 0.0;
+        if (act0) st.pre[(PD_GR + i) % FF_AHEAD] = ff_load_row(col, PD_GR + i, H, W, act1);
     }
 #define FF_STEP(S)                                                                                              \
     if (y0 + S > H) break;                                                                                      \
