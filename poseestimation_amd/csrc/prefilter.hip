@@ -214,14 +214,25 @@ static int build_filter_tables(pd_ctx* ctx) {
 #define KP_PIX 256
 __global__ void __launch_bounds__(256)
 k_heat_planar(const float* __restrict__ lo, int npix, float* __restrict__ planar, unsigned int* __restrict__ absmax_bits) {
-    __shared__ float tile[KP_PIX * PD_CH_HEAT];
+    __shared__ __align__(16) float tile[KP_PIX * PD_CH_HEAT];
     __shared__ float s_red[4];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int p0 = blockIdx.x * KP_PIX;
     const int np = min(KP_PIX, npix - p0);
     const float* src = lo + ((size_t)b * npix + p0) * PD_CH_HEAT;
     float m = 0.f;
-    for (int i = tid; i < np * PD_CH_HEAT; i += 256) {
+    const int n = np * PD_CH_HEAT;
+    int done = 0;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {  // 16 bytes per load: four times the bytes in flight per thread
+        const int n4 = n >> 2;
+        for (int i = tid; i < n4; i += 256) {
+            const float4 v = ((const float4*)src)[i];
+            ((float4*)tile)[i] = v;
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        done = 4 * n4;
+    }
+    for (int i = done + tid; i < n; i += 256) {
         const float v = src[i];
         tile[i] = v;
         m = fmaxf(m, fabsf(v));
