@@ -423,7 +423,7 @@ __device__ __forceinline__ float4 lds4(const float4* base, unsigned byte_off) {
 
 template <bool POW2, int NS>
 __global__ void __launch_bounds__(256, 4)
-k_resize_tiles(AvgArgs a, int groups_per_block) {
+k_resize_tiles(AvgArgs a, int groups_per_block, int images_per_block, int n_images) {
     __shared__ float4 patch[FT_PATCH];
     __shared__ float4 hsum[FT_HSUM];
     __shared__ float4 srcp[FT_SRC];
@@ -446,7 +446,9 @@ k_resize_tiles(AvgArgs a, int groups_per_block) {
     const bool inside = X0 + px < a.W && Y0 + py < a.H;
     const int X = min(X0 + px, a.W - 1), Y = min(Y0 + py, a.H - 1);
     const int Ylast = min(Y0 + FT_TH - 1, a.H - 1), Xlast = min(X0 + FT_TW - 1, a.W - 1);
-    const int b = blockIdx.z;
+    // a workgroup takes its tile in several images, one after the other: what the tile's threads
+    // touch is worked out once for all of them
+    const int b_begin = blockIdx.z * images_per_block, b_end = min(n_images, b_begin + images_per_block);
     const int n_groups = (a.C + FT_CH - 1) / FT_CH;
     const int g_begin = blockIdx.y * groups_per_block, g_end = min(n_groups, g_begin + groups_per_block);
 
@@ -533,11 +535,16 @@ k_resize_tiles(AvgArgs a, int groups_per_block) {
 
     float amax = 0.f;
     float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread's source pixel of the coming round
-    if (g_begin < g_end && th[0].o0 != ~0u)
-        pre = load_channels(a.s[0].lo + (size_t)b * a.s[0].hs * a.s[0].ws * a.C + g_begin * FT_CH + th[0].o0,
+    if (g_begin < g_end && b_begin < b_end && th[0].o0 != ~0u)
+        pre = load_channels(a.s[0].lo + (size_t)b_begin * a.s[0].hs * a.s[0].ws * a.C + g_begin * FT_CH + th[0].o0,
                             min(FT_CH, a.C - g_begin * FT_CH));
-    for (int g = g_begin; g < g_end; ++g) {
+    const int n_rounds = g_begin < g_end ? (b_end - b_begin) * (g_end - g_begin) : 0;
+    int b = b_begin, g = g_begin;
+    for (int it = 0; it < n_rounds; ++it) {
         const int ch0 = g * FT_CH;
+        // the (image, channel group) after this one
+        const bool last_group = g + 1 == g_end;
+        const int b_next = last_group ? b + 1 : b, ch_next = last_group ? g_begin * FT_CH : ch0 + FT_CH;
         const int nch = min(FT_CH, a.C - ch0);
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         // The packed fields are re-read as opaque values in every round: otherwise the compiler
@@ -564,10 +571,10 @@ k_resize_tiles(AvgArgs a, int groups_per_block) {
             if (m + 1 < NS) {
                 if (th[m + 1].o0 != ~0u)
                     pre = load_channels(a.s[m + 1].lo + (size_t)b * a.s[m + 1].hs * a.s[m + 1].ws * a.C + ch0 + th[m + 1].o0, nch);
-            } else if (g + 1 < g_end) {
+            } else if (it + 1 < n_rounds) {
                 if (th[0].o0 != ~0u)
-                    pre = load_channels(a.s[0].lo + (size_t)b * a.s[0].hs * a.s[0].ws * a.C + (ch0 + FT_CH) + th[0].o0,
-                                        min(FT_CH, a.C - (ch0 + FT_CH)));
+                    pre = load_channels(a.s[0].lo + (size_t)b_next * a.s[0].hs * a.s[0].ws * a.C + ch_next + th[0].o0,
+                                        min(FT_CH, a.C - ch_next));
             }
             // A: horizontal sums
 #pragma unroll
@@ -648,8 +655,15 @@ k_resize_tiles(AvgArgs a, int groups_per_block) {
                 amax = fmaxf(amax, (float)fabs(acc3));
             }
         }
+        if (last_group) {
+            if (a.absmax) pd_wave_absmax(amax, a.absmax + b);
+            amax = 0.f;
+            g = g_begin;
+            ++b;
+        } else {
+            ++g;
+        }
     }
-    if (a.absmax) pd_wave_absmax(amax, a.absmax + b);
 }
 
 // Whether every tile's patch of the second resize (crop -> H x W) fits the staging areas of
@@ -682,12 +696,12 @@ static bool patches_fit(int crop_h, int crop_w, int H, int W) {
 }
 
 template <bool POW2>
-static void launch_tiles(int ns, dim3 grid, hipStream_t stream, const AvgArgs& a, int gpb) {
+static void launch_tiles(int ns, dim3 grid, hipStream_t stream, const AvgArgs& a, int gpb, int ipb, int B) {
     switch (ns) {
-        case 1: hipLaunchKernelGGL((k_resize_tiles<POW2, 1>), grid, dim3(256), 0, stream, a, gpb); break;
-        case 2: hipLaunchKernelGGL((k_resize_tiles<POW2, 2>), grid, dim3(256), 0, stream, a, gpb); break;
-        case 3: hipLaunchKernelGGL((k_resize_tiles<POW2, 3>), grid, dim3(256), 0, stream, a, gpb); break;
-        default: hipLaunchKernelGGL((k_resize_tiles<POW2, 4>), grid, dim3(256), 0, stream, a, gpb); break;
+        case 1: hipLaunchKernelGGL((k_resize_tiles<POW2, 1>), grid, dim3(256), 0, stream, a, gpb, ipb, B); break;
+        case 2: hipLaunchKernelGGL((k_resize_tiles<POW2, 2>), grid, dim3(256), 0, stream, a, gpb, ipb, B); break;
+        case 3: hipLaunchKernelGGL((k_resize_tiles<POW2, 3>), grid, dim3(256), 0, stream, a, gpb, ipb, B); break;
+        default: hipLaunchKernelGGL((k_resize_tiles<POW2, 4>), grid, dim3(256), 0, stream, a, gpb, ipb, B); break;
     }
 }
 
@@ -735,11 +749,17 @@ int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, 
         int chunks = (int)((4096 + (size_t)tiles * B - 1) / ((size_t)tiles * B));
         chunks = chunks < 1 ? 1 : (chunks > n_groups ? n_groups : chunks);
         const int gpb = (n_groups + chunks - 1) / chunks;
-        const dim3 tgrid((tiles + 7) / 8 * 8, (n_groups + gpb - 1) / gpb, B);
+        // and several images per workgroup while that leaves sixteen workgroups for every slot of
+        // the chip (the set-up of a tile is a fifth of what one image's channel groups cost)
+        int ipb = (int)((size_t)tiles * B / 16384);
+        ipb = ipb < 1 ? 1 : (ipb > 8 ? 8 : ipb);
+        static const int ipb_env = getenv("PD_RESIZE_IMAGES") ? atoi(getenv("PD_RESIZE_IMAGES")) : 0;  // comparison runs
+        if (ipb_env > 0) ipb = ipb_env;
+        const dim3 tgrid((tiles + 7) / 8 * 8, (n_groups + gpb - 1) / gpb, (B + ipb - 1) / ipb);
         if (pow2)
-            launch_tiles<true>(n_scales, tgrid, ctx->stream, a, gpb);
+            launch_tiles<true>(n_scales, tgrid, ctx->stream, a, gpb, ipb, B);
         else
-            launch_tiles<false>(n_scales, tgrid, ctx->stream, a, gpb);
+            launch_tiles<false>(n_scales, tgrid, ctx->stream, a, gpb, ipb, B);
     } else if (pow2 && !direct)
         hipLaunchKernelGGL((k_resize_fused<true, false>), grid, dim3(256), 0, ctx->stream, a);
     else if (pow2)
