@@ -763,6 +763,8 @@ static void choose_pairs_kernel(pd_ctx* ctx) {
 }
 
 extern "C" int pd_decode_fullres(pd_ctx* ctx, double thre1, double thre2) {
+    PD_CHECK_CTX(ctx);
+    choose_pairs_kernel(ctx);  // (inside pd_decode_batch: the same answer as the one its launch-sequence key holds)
     int rc = pd_peaks(ctx, thre1);
     if (rc != PD_OK) return rc;
     rc = pd_connections(ctx, thre2);
