@@ -297,6 +297,16 @@ __device__ __forceinline__ void pd_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+// The value of the lane before / behind this one (0 at the ends of the wavefront): a whole-wave
+// shift by one in the data path of a move, where __shfl_up / __shfl_down go through the LDS
+// crossbar with an address computation and a wait.
+__device__ __forceinline__ float pd_lane_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float pd_lane_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 // scipy mode='reflect' index (d c b a | a b c d | d c b a) for any offset.
 __device__ __forceinline__ int pd_reflect(int i, int n) {
     if (i >= 0 && i < n) return i;

@@ -632,7 +632,7 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
 #pragma unroll
         for (int j = 1; j <= 8; ++j) {
             const float c = S[j];
-            const float left = __shfl_up(c, 1), right = __shfl_down(c, 1);
+            const float left = pd_lane_prev(c), right = pd_lane_next(c);
             const float ce = c + cur.e2;
             const float m4 = fmaxf(fmaxf(S[j - 1], S[j + 1]), fmaxf(left, right));
             hits |= (c > cur.thr_lo && ce >= m4) ? (1u << j) : 0u;
