@@ -266,6 +266,12 @@ __global__ void k_nms_simple(const double* sm, const double* ori, int H, int W, 
     emit_peak(is_peak, Y, X, score, raw + (size_t)plane * PK, raw_count + plane, PK);
 }
 
+// Column strips of a plane: workgroups of at most four wavefronts (a row step is a chain of
+// dependent float64 sums, and narrow workgroups pack onto a CU where one wide one leaves its
+// registers idle: two strips of 256 threads take 1.22 ms at 368^2, batch 64, one of 384
+// threads 1.76 ms, although the strips redo 26 halo columns each), and among those the split
+// that wastes the fewest threads.
+#define NT_PREFERRED 256
 static void pick_strips(int W, int* n_strips, int* strip_w, int* nt) {
     int best_n = 1, best_w = W, best_nt = 0;
     double best_eff = -1.0;
@@ -273,6 +279,7 @@ static void pick_strips(int W, int* n_strips, int* strip_w, int* nt) {
         const int sw = (W + n - 1) / n;
         const int cols = n == 1 ? W : sw + 2 * (PD_GR + 1);
         const int t = ((cols + 63) / 64) * 64;
+        if (t > NT_PREFERRED && n < 64) continue;
         if (t > NTMAX) continue;
         const double eff = (double)W / ((double)n * t);
         if (eff > best_eff + 1e-9) {
