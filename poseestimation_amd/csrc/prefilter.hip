@@ -312,15 +312,16 @@ k_cells(CellArgs a) {
     float* copy = a.nhwc ? a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w : nullptr;
     const int NT = blockDim.x;
     float m = 0.f;
-    for (int i0 = 0; i0 < h * w; i0 += NT * 8) {
-        float t[8];
+    // (nine per thread and round: a 46 x 46 plane is one round of 256 threads)
+    for (int i0 = 0; i0 < h * w; i0 += NT * 9) {
+        float t[9];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 9; ++k) {
             const int i = i0 + k * NT + tid;
             t[k] = i < h * w ? (pix ? pix[(size_t)i * PD_CH_HEAT] : img[i]) : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 9; ++k) {
             const int i = i0 + k * NT + tid;
             if (i < h * w) {
                 A[i] = fabsf(t[k]);
