@@ -709,18 +709,24 @@ struct VerifyArgs {
     int PK;
 };
 
-// Exact float64 decision for every candidate.  32 lanes per candidate, 8 candidates per
+// Exact float64 decision for every candidate.  32 lanes per candidate, VF_CAND candidates per
 // workgroup pass, workgroups stride over the global list.  Lane l < 27 owns column
 // X + l - 13: it forms the horizontal 4-tap sums of the (at most 8) source rows that the
 // 27 bicubic rows Y-13 .. Y+13 draw on, then the 27 vertical sums and the three y-pass
 // sums (rows Y-1, Y, Y+1); five lanes finish the x pass (centre and four neighbours).
 // FULL: the unsmoothed map is read from the float64 planes instead of being formed from the
 // network output.
+// Threads of a verification workgroup: 32 lanes per candidate.  The LDS a candidate needs (5 KB)
+// bounds how many are in flight on a CU; small workgroups fill that bound without a remainder.
+#define VF_NT 128
+#define VF_CAND (VF_NT / 32)
+
 template <bool FULL>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(VF_NT)
 k_verify(VerifyArgs a) {
-    __shared__ double ypL[8][3][28];
-    __shared__ float hvL[8][256];
+    __shared__ double ypL[VF_CAND][3][28];
+    __shared__ float hvL[8][VF_NT];
+    __shared__ float uL[FULL ? 1 : 27][VF_NT];  // a lane's 27 bicubic values of its column
     __shared__ float4 s_up[8];
     __shared__ int s_pref[KF_NSEG + 1];
     const int tid = threadIdx.x;
@@ -732,7 +738,7 @@ k_verify(VerifyArgs a) {
     segment_prefix(a.cand_n, a.cand_seg_cap, s_pref, tid);
     const int total = s_pref[KF_NSEG];
     const int H = a.H, W = a.W, h = a.h, w = a.w;
-    for (int base = blockIdx.x * 8; base < total; base += gridDim.x * 8) {
+    for (int base = blockIdx.x * VF_CAND; base < total; base += gridDim.x * VF_CAND) {
         const int ci = base + half;
         bool active = ci < total;
         int Y = 0, X = 0, plane = 0, plane_total = 0;
@@ -780,16 +786,21 @@ k_verify(VerifyArgs a) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 hvL[q][tid] = ((sv[q].x * ac.x + sv[q].y * ac.y) + sv[q].z * ac.z) + sv[q].w * ac.w;
+            // The 27 values of the column go through an LDS column of this lane, written by a
+            // rolled loop: unrolled, the compiler forms the tap rows and weights of all 27 before
+            // the first sum and the kernel needs 238 registers instead of a good hundred.
+            if (!FULL) {
+#pragma unroll 1
+                for (int i = 0; i < 27; ++i) {
+                    const int r = pd_reflect(Y - 13 + i, H);
+                    const int d = min(pd_up8_ofs(r) - ymin, 4);
+                    const float4 bc = s_up[pd_up8_phase(r)];
+                    uL[i][tid] = ((hvL[d][tid] * bc.x + hvL[d + 1][tid] * bc.y) + hvL[d + 2][tid] * bc.z) + hvL[d + 3][tid] * bc.w;
+                }
+            }
             double u[27];
 #pragma unroll
-            for (int i = 0; i < 27; ++i) {
-                const int r = pd_reflect(Y - 13 + i, H);
-                const int d = min(pd_up8_ofs(r) - ymin, 4);
-                const float4 bc = s_up[pd_up8_phase(r)];
-                const float v = ((hvL[d][tid] * bc.x + hvL[d + 1][tid] * bc.y) + hvL[d + 2][tid] * bc.z) +
-                                hvL[d + 3][tid] * bc.w;
-                u[i] = (double)v;
-            }
+            for (int i = 0; i < 27; ++i) u[i] = (double)uL[i][tid];
             u13 = u[13];
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
@@ -973,10 +984,10 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     v.raw = ctx->raw;
     v.raw_count = ctx->raw_count;
     v.PK = ctx->cfg.max_peaks_per_part;
-    int vblocks = B * 12;
-    if (vblocks > 1024) vblocks = 1024;
+    int vblocks = B * 12 * (256 / VF_NT);
+    if (vblocks > 1024 * (256 / VF_NT)) vblocks = 1024 * (256 / VF_NT);
     pd_prof_begin(ctx, PD_STAGE_VERIFY);
-    hipLaunchKernelGGL(k_verify<false>, dim3(vblocks), dim3(256), 0, ctx->stream, v);
+    hipLaunchKernelGGL(k_verify<false>, dim3(vblocks), dim3(VF_NT), 0, ctx->stream, v);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     // planes whose candidates did not fit; the same kernel then orders every image's peaks
@@ -1234,10 +1245,10 @@ int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr) {
     v.raw = ctx->raw;
     v.raw_count = ctx->raw_count;
     v.PK = ctx->cfg.max_peaks_per_part;
-    int vblocks = B * 12;
-    if (vblocks > 1024) vblocks = 1024;
+    int vblocks = B * 12 * (256 / VF_NT);
+    if (vblocks > 1024 * (256 / VF_NT)) vblocks = 1024 * (256 / VF_NT);
     pd_prof_begin(ctx, PD_STAGE_VERIFY);
-    hipLaunchKernelGGL(k_verify<true>, dim3(vblocks), dim3(256), 0, ctx->stream, v);
+    hipLaunchKernelGGL(k_verify<true>, dim3(vblocks), dim3(VF_NT), 0, ctx->stream, v);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     return pd_launch_stream_exact(ctx, thr, 0, nullptr, ctx->cand_count, CK, 1);
