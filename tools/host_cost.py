@@ -39,3 +39,34 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print('60 enqueues: host', (t1 - t0) / 60 * 1e6, 'us each; drained after', (t2 - t0) / 60 * 1e6, 'us each')
 for e in engs: e.ctx.fetch()
+
+# GPU-side view of the same steady state: an event pair around every decode on its context's
+# stream (chain = time from the first kernel's turn to the end of the last; gap = time the
+# stream then sits idle until the next decode's turn)
+if os.environ.get('PD_HC_EVENTS') == '1':
+    streams = [torch.cuda.ExternalStream(int(e.ctx.stream)) for e in engs]
+    ev = [[] for _ in engs]
+    pend = []
+    for i in range(400):
+        c = i % NC
+        e = engs[c]
+        if len(pend) == NC:
+            pend.pop(0).ctx.fetch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(streams[c])
+        e.enqueue_device(dh.data_ptr(), dp.data_ptr(), B, H // 8, W // 8, (H, W))
+        e1.record(streams[c])
+        ev[c].append((e0, e1))
+        pend.append(e)
+    while pend:
+        pend.pop(0).ctx.fetch()
+    torch.cuda.synchronize()
+    chain, gap = [], []
+    for c in range(NC):
+        for k in range(20, len(ev[c])):
+            chain.append(ev[c][k][0].elapsed_time(ev[c][k][1]) * 1e3)
+            gap.append(ev[c][k - 1][1].elapsed_time(ev[c][k][0]) * 1e3)
+    chain.sort(); gap.sort()
+    print('events: chain median %.1f us (p10 %.1f, p90 %.1f); idle gap before a chain median %.1f us (p10 %.1f, p90 %.1f)'
+          % (chain[len(chain) // 2], chain[len(chain) // 10], chain[9 * len(chain) // 10],
+             gap[len(gap) // 2], gap[len(gap) // 10], gap[9 * len(gap) // 10]))
