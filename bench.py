@@ -71,6 +71,9 @@ def main():
                     help='experiments: no event pair around the roofline kernel in the timed region')
     ap.add_argument('--contexts', type=int, default=0,
                     help='decode contexts (HIP streams) per GPU, used round-robin (0: 4, 3 in the round pipeline; 1 for the multi-scale workload, whose kernels fill the chip by themselves)')
+    ap.add_argument('--depth', type=int, default=0,
+                    help='fetch pipeline: contexts per stream, used in turn, so that a stream holds that many '
+                         'decodes (0: 2; the round pipeline keeps its own depth)')
     ap.add_argument('--pipeline', default='', choices=['', 'fetch', 'rounds'],
                     help='N = 1 only.  fetch: every decode copies its full packed results (with the connection '
                          'lists) to the host; rounds: the N > 1 pipeline with a plain device-to-host copy in place of '
@@ -222,6 +225,15 @@ def run_single(env):
     engs = [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=env['local_rank'],
                          max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000)
             for _ in range(n_ctx)]
+    # fetch pipeline: a second context on every stream, used in turn with the first, so that a
+    # stream already holds the next decode while the host fetches the results of the last
+    depth = 1
+    if not rounds:
+        depth = args.depth if args.depth > 0 else 2
+        for d in range(1, depth):
+            engs += [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=env['local_rank'],
+                                  max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000,
+                                  share_stream_with=engs[i]) for i in range(n_ctx)]
     eng = engs[0]
     gather_cap = 1 << 18      # per rank and decode: header, count tables, peaks, person rows
     while gather_cap < B * 4096:
@@ -470,7 +482,7 @@ def run_single(env):
             'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': desc, 'name': args.workload, 'batch_per_gpu': B * per_step, 'mode': args.mode,
-                       'contexts_per_gpu': len(engs), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
+                       'contexts_per_gpu': len(engs), 'streams_per_gpu': n_ctx, 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
                        'people_per_image': list(people) if isinstance(people, tuple) else people,
                        'inputs': 'device-resident network outputs, %d distinct batches of %.1f MB used in turn '
                                  '(the host-to-device copy of predict.py:61 is outside the timed region; '

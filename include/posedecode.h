@@ -89,6 +89,15 @@ int pd_set_impl(pd_ctx* ctx, int impl);
 /* The HIP stream the context launches on (a hipStream_t), for callers that time
  * launches with events or order their own work against it. */
 void* pd_stream(pd_ctx* ctx);
+/* Puts ctx on the stream of another context of the same GPU (ctx gives up its own).  Two
+ * contexts used in turn on one stream keep that stream two decodes deep: the second context's
+ * pd_decode_batch queues behind the first's while the host still fetches the first's results
+ * (pd_sync_totals / pd_fetch of a sharing context wait for that context's own last decode, not
+ * for the stream).  The chip serves four hardware queues at a time, so more streams do not help;
+ * a second decode on each does.  Both contexts must be driven by one host thread (no pd_submit),
+ * and the owner must outlive ctx.  No counterpart in the reference (it decodes one image at a
+ * time on the CPU). */
+int pd_share_stream(pd_ctx* ctx, pd_ctx* owner);
 
 /* ---- stage 1: predict.py:51-72 (multi-scale upsample, un-pad, resize, average) ----
  * heat[m] is (B, hs[m], ws[m], 19) float32, paf[m] is (B, hs[m], ws[m], 38):

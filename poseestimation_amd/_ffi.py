@@ -18,7 +18,7 @@ F32, F64, U8 = 0, 1, 2
 IMPL_FAST, IMPL_SIMPLE, IMPL_STREAM = 0, 1, 2
 
 EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mode', 'pd_set_impl',
-           'pd_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
+           'pd_stream', 'pd_share_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
            'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay', 'pd_set_host_results',
@@ -103,6 +103,7 @@ def lib():
     L.pd_set_impl.argtypes = [vp, i32]
     L.pd_stream.argtypes = [vp]
     L.pd_stream.restype = vp
+    L.pd_share_stream.argtypes = [vp, vp]
     L.pd_upsample_avg.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   i32, i32, i32, i32]
@@ -206,6 +207,11 @@ class Context:
     @property
     def stream(self):
         return self.L.pd_stream(self._h)
+
+    def share_stream(self, owner):
+        """Launch on ``owner``'s stream from now on (see pd_share_stream); keeps ``owner`` alive."""
+        self.check(self.L.pd_share_stream(self._h, owner._h))
+        self._stream_owner = owner
 
     def set_mode(self, mode):
         self.check(self.L.pd_set_mode(self._h, mode))

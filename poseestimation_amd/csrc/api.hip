@@ -189,7 +189,8 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
     free(ctx->prof_stage);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
+    if (ctx->stream && !ctx->stream_shared) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PD_OK;
 }
@@ -725,7 +726,12 @@ static int prof_harvest(pd_ctx* ctx) {
 
 // Waits for the packed results and completes the host mirror.
 static int finish_results(pd_ctx* ctx) {
-    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (on a shared stream: for this context's last decode only, not for what the other context
+    // has queued behind it)
+    if (ctx->stream_shared && ctx->done_valid)
+        PD_HIP(ctx, hipEventSynchronize(ctx->done_ev));
+    else
+        PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->prof_n > 0) {
         int rc = prof_harvest(ctx);
         if (rc != PD_OK) return rc;
@@ -779,10 +785,43 @@ extern "C" int pd_decode_fullres(pd_ctx* ctx, double thre1, double thre2) {
     return pd_pack(ctx);
 }
 
+static int decode_batch_enqueue(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H, int W,
+                                double thre1, double thre2, int mem);
+
 extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H,
                                int W, double thre1, double thre2, int mem) {
     PD_CHECK_CTX(ctx);
     if (!heat || !paf) PD_FAIL(ctx, PD_E_INVALID, "pd_decode_batch: heat and paf are required");
+    ctx->done_valid = 0;
+    int rc = decode_batch_enqueue(ctx, heat, paf, B, h, w, H, W, thre1, thre2, mem);
+    if (rc == PD_OK && ctx->stream_shared) {
+        PD_HIP(ctx, hipEventRecord(ctx->done_ev, ctx->stream));
+        ctx->done_valid = 1;
+    }
+    return rc;
+}
+
+extern "C" int pd_share_stream(pd_ctx* ctx, pd_ctx* owner) {
+    PD_CHECK_CTX(ctx);
+    if (!owner || owner == ctx || owner->stream_shared || ctx->stream_shared)
+        PD_FAIL(ctx, PD_E_INVALID, "pd_share_stream: the owner must be another context with a stream of its own, and this one must still have its own");
+    if (owner->cfg.device_id != ctx->cfg.device_id) PD_FAIL(ctx, PD_E_INVALID, "pd_share_stream: the contexts are on different GPUs");
+    if (ctx->worker) PD_FAIL(ctx, PD_E_STATE, "pd_share_stream: not for a context with a launcher thread (pd_submit)");
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = drop_graphs(ctx);
+    if (rc != PD_OK) return rc;
+    if (!ctx->done_ev) PD_HIP(ctx, hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming));
+    PD_HIP(ctx, hipStreamDestroy(ctx->stream));
+    ctx->stream = owner->stream;
+    ctx->stream_shared = 1;
+    ctx->done_valid = 0;
+    ctx->gen++;
+    return PD_OK;
+}
+
+static int decode_batch_enqueue(pd_ctx* ctx, const float* heat, const float* paf, int B, int h, int w, int H, int W,
+                                double thre1, double thre2, int mem) {
     int rc = pd_set_lowres(ctx, heat, paf, B, h, w, H, W, mem);
     if (rc != PD_OK) return rc;
     if (mem != PD_MEM_DEVICE || !ctx->use_graph) {
@@ -937,6 +976,7 @@ extern "C" int pd_submit(pd_ctx* ctx, const float* heat, const float* paf, int B
                          double thre1, double thre2, void* skeleton_ptr, uint64_t skeleton_capacity) {
     PD_CHECK_CTX(ctx);
     if (!heat || !paf) PD_FAIL(ctx, PD_E_INVALID, "pd_submit: heat and paf are required");
+    if (ctx->stream_shared) PD_FAIL(ctx, PD_E_STATE, "pd_submit: not for a context on another context's stream (two threads would launch on it)");
     if (!ctx->worker) {
         ctx->wk_mu = new std::mutex();
         ctx->wk_cv = new std::condition_variable();

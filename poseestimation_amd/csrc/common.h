@@ -186,6 +186,11 @@ struct pd_ctx {
     int32_t* zero_block; // raw_count | cand_count + list counters: zero at the start of every decode
     size_t zero_bytes;
     int zero_clean;      // the block is zero (or a kernel that zeroes it is queued): pd_pack leaves it so
+    // Two contexts may launch on one stream (pd_share_stream): the second decode queues behind the
+    // first, and a context then waits for its own last decode through an event, not for the stream.
+    int stream_shared;    // the stream belongs to another context: not destroyed with this one
+    hipEvent_t done_ev;   // recorded behind every pd_decode_batch of a context that shares a stream
+    int done_valid;
     int32_t* pack_ticket; // behind the block: arrival counter of k_parse_pack, zero between launches (NULL: not available)
     int64_t* fstats;     // what pd_filter_stats reports, summed up by k_sort_peaks before the counters go
     RawPeak* raw;        // [B][18][PK] unordered

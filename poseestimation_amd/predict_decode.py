@@ -74,12 +74,16 @@ class DecodeEngine:
     device pointers with ``device=True``) and returns :class:`Results`."""
 
     def __init__(self, max_batch, max_h=368, max_w=368, mode='D', device_id=0, max_peaks_per_part=128,
-                 max_persons=128, max_pairs_per_image=32768, fullres=False):
+                 max_persons=128, max_pairs_per_image=32768, fullres=False, share_stream_with=None):
+        """``share_stream_with``: another engine of the same GPU whose HIP stream this one uses
+        too; the two, used in turn by one thread, keep that stream two decodes deep."""
         self.mode = _MODES[mode]
         self.ctx = _ffi.Context(device_id=device_id, max_batch=max_batch, max_h=max_h, max_w=max_w,
                                 max_peaks_per_part=max_peaks_per_part, max_persons=max_persons,
                                 max_pairs_per_image=max_pairs_per_image, fullres=fullres)
         self.ctx.set_mode(self.mode)
+        if share_stream_with is not None:
+            self.ctx.share_stream(share_stream_with.ctx)
 
     def close(self):
         self.ctx.close()

@@ -167,3 +167,37 @@ def test_pd_fetch_and_pd_packed_device_agree_with_the_host_mirror():
     assert dev_bytes(part_p, 3 * 18 * 4).view(np.int32).reshape(3, 18).tolist() == a['part_count'].tolist()
     assert dev_bytes(pers_p, 12).view(np.int32).tolist() == a['person_count'].tolist()
     eng.close()
+
+
+def test_two_contexts_on_one_stream_keep_their_results_apart():
+    """pd_share_stream: a second context on the first one's stream; decodes are enqueued on both
+    before either is fetched (device-resident inputs, so the recorded launch sequences are used
+    too), and each fetch returns its own context's results."""
+    import torch
+    from poseestimation_amd import synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 184
+    batches = [synth.batch(3, H, W, (1, 3), seed0=s, paf_order='xy') for s in (910, 920, 930)]
+    dev = [(torch.from_numpy(h).cuda(), torch.from_numpy(p).cuda()) for h, p in batches]
+    plain = DecodeEngine(3, H, W, mode='D')
+    want = [plain.decode_batch(h, p).packed for h, p in batches]
+    a = DecodeEngine(3, H, W, mode='D')
+    b = DecodeEngine(3, H, W, mode='D', share_stream_with=a)
+    assert a.ctx.stream == b.ctx.stream
+    for it in range(8):
+        ka, kb = it % 3, (it + 1) % 3
+        a.enqueue_device(dev[ka][0].data_ptr(), dev[ka][1].data_ptr(), 3, 23, 23, (H, W))
+        b.enqueue_device(dev[kb][0].data_ptr(), dev[kb][1].data_ptr(), 3, 23, 23, (H, W))
+        got_a = a.fetch().packed
+        a.enqueue_device(dev[kb][0].data_ptr(), dev[kb][1].data_ptr(), 3, 23, 23, (H, W))   # queued behind b's decode
+        got_b = b.fetch().packed
+        got_a2 = a.fetch().packed
+        for key in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
+            assert np.array_equal(got_a[key], want[ka][key]), (it, key)
+            assert np.array_equal(got_b[key], want[kb][key]), (it, key)
+            assert np.array_equal(got_a2[key], want[kb][key]), (it, key)
+    with pytest.raises(Exception):
+        b.ctx.submit(dev[0][0].data_ptr(), dev[0][1].data_ptr(), 3, 23, 23, H, W, 0.1, 0.05, 0, 0)
+    b.close()
+    a.close()
+    plain.close()
