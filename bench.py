@@ -73,7 +73,7 @@ def main():
                     help='decode contexts (HIP streams) per GPU, used round-robin (0: 4, 3 in the round pipeline; 1 for the multi-scale workload, whose kernels fill the chip by themselves)')
     ap.add_argument('--depth', type=int, default=0,
                     help='fetch pipeline: contexts per stream, used in turn, so that a stream holds that many '
-                         'decodes (0: 2; the round pipeline keeps its own depth)')
+                         'decodes (0: 2 for maps of at most 4096 pixels, else 1; the round pipeline keeps its own depth)')
     ap.add_argument('--pipeline', default='', choices=['', 'fetch', 'rounds'],
                     help='N = 1 only.  fetch: every decode copies its full packed results (with the connection '
                          'lists) to the host; rounds: the N > 1 pipeline with a plain device-to-host copy in place of '
@@ -229,7 +229,8 @@ def run_single(env):
     # stream already holds the next decode while the host fetches the results of the last
     depth = 1
     if not rounds:
-        depth = args.depth if args.depth > 0 else 2
+        # (decodes of large maps take a millisecond and more: the host's turn-around is nothing beside it)
+        depth = args.depth if args.depth > 0 else (2 if h * w <= 4096 else 1)
         for d in range(1, depth):
             engs += [DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=args.mode, device_id=env['local_rank'],
                                   max_peaks_per_part=128, max_persons=128, max_pairs_per_image=40000,
