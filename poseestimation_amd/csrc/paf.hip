@@ -426,14 +426,20 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     return PD_OK;
 }
 
-extern int pd_match_cap_override;
+// (tests set this to force the arg-max form)
+extern "C" int pd_match_cap_override;
 int pd_match_cap_override = 0;
 
 int pd_launch_match(pd_ctx* ctx) {
     MatchArgs a;
     a.PK = ctx->cfg.max_peaks_per_part;
     a.max_pairs = ctx->cfg.max_pairs_per_image;
-    a.cap = pd_match_cap_override > 0 ? pd_match_cap_override : 2048;
+    // Surviving pairs of a limb that the wavefront's sort list holds (more: the arg-max form, same
+    // result).  512 covers 22 x 22 peaks with every pair surviving; the list is 12 bytes per entry
+    // of a one-wavefront workgroup's LDS, and with 2048 entries (25 KB) six such workgroups filled
+    // a CU's LDS and kept the other contexts' kernels out (1.15 -> 1.18 M images/s at 368^2,
+    // 298 -> 313 k at 656^2 with 30 people).
+    a.cap = pd_match_cap_override > 0 ? pd_match_cap_override : 512;
     a.pair_score = ctx->pair_score;
     a.pair_off = ctx->pair_off;
     a.part_count = ctx->part_count;

@@ -318,3 +318,31 @@ def test_pair_scoring_with_and_without_its_pretest_agree():
     for b in range(4):
         _assert_image(first, b, _oracle_image(crowd_h[b], crowd_p[b], 'D', H, W), 'D')
     eng.close()
+
+
+@pytest.mark.parametrize('cap', [4, 64])
+def test_matching_beyond_the_sort_list_takes_the_arg_max_form(cap):
+    """A limb with more surviving pairs than the wavefront's sort list holds is matched by repeated
+    arg-max instead: the same connections.  The list is shrunk to force it (crowded scene, both
+    modes' tie rules covered by the oracle comparison)."""
+    import ctypes as C
+    from poseestimation_amd import _ffi, synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 368
+    heat, paf = synth.batch(3, H, W, 12, seed0=8300, paf_order='xy')
+    lib = C.CDLL(_ffi.LIB_PATH)
+    knob = C.c_int.in_dll(lib, 'pd_match_cap_override')
+    eng = DecodeEngine(max_batch=3, max_h=H, max_w=W, mode='D', max_peaks_per_part=128, max_persons=128,
+                       max_pairs_per_image=40000)
+    knob.value = cap
+    try:
+        res = eng.decode_batch(heat, paf)
+    finally:
+        knob.value = 0
+    n_conn = 0
+    for b in range(3):
+        want = _oracle_image(heat[b], paf[b], 'D', H, W)
+        n_conn += max(len(c) for c in want[1])
+        _assert_image(res, b, want, 'D')
+    assert n_conn > 3 * cap or cap > 4      # with cap 4 every busy limb overflows the list
+    eng.close()
