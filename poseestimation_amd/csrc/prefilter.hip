@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(VF_NT)
 k_verify(VerifyArgs a) {
     __shared__ double ypL[VF_CAND][3][28];
     __shared__ float hvL[8][VF_NT];
-    __shared__ float uL[FULL ? 1 : 27][VF_NT];  // a lane's 27 bicubic values of its column
+    __shared__ int rowL[VF_CAND][28];  // per candidate: first tap row | weight phase << 8 of its 27 window rows
     __shared__ float4 s_up[8];
     __shared__ int s_pref[KF_NSEG + 1];
     const int tid = threadIdx.x;
@@ -786,21 +786,23 @@ k_verify(VerifyArgs a) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 hvL[q][tid] = ((sv[q].x * ac.x + sv[q].y * ac.y) + sv[q].z * ac.z) + sv[q].w * ac.w;
-            // The 27 values of the column go through an LDS column of this lane, written by a
-            // rolled loop: unrolled, the compiler forms the tap rows and weights of all 27 before
-            // the first sum and the kernel needs 238 registers instead of a good hundred.
-            if (!FULL) {
-#pragma unroll 1
-                for (int i = 0; i < 27; ++i) {
-                    const int r = pd_reflect(Y - 13 + i, H);
-                    const int d = min(pd_up8_ofs(r) - ymin, 4);
-                    const float4 bc = s_up[pd_up8_phase(r)];
-                    uL[i][tid] = ((hvL[d][tid] * bc.x + hvL[d + 1][tid] * bc.y) + hvL[d + 2][tid] * bc.z) + hvL[d + 3][tid] * bc.w;
-                }
+            // Which source rows and which weights the 27 rows of the window take depends on Y alone:
+            // lane i of the candidate works it out for row i, once, and all lanes read it back.
+            // (Worked out per lane inside the unrolled loop, the compiler formed all 27 first and the
+            // kernel held 238 registers.)
+            {
+                const int r = pd_reflect(Y - 13 + l, H);
+                rowL[half][l] = min(pd_up8_ofs(r) - ymin, 4) | (pd_up8_phase(r) << 8);
             }
+            pd_wave_sync();  // the 32 lanes of a candidate share a wavefront
             double u[27];
 #pragma unroll
-            for (int i = 0; i < 27; ++i) u[i] = (double)uL[i][tid];
+            for (int i = 0; i < 27; ++i) {
+                const int m = rowL[half][i];
+                const int d = m & 255;
+                const float4 bc = s_up[m >> 8];
+                u[i] = (double)(((hvL[d][tid] * bc.x + hvL[d + 1][tid] * bc.y) + hvL[d + 2][tid] * bc.z) + hvL[d + 3][tid] * bc.w);
+            }
             u13 = u[13];
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
