@@ -486,13 +486,23 @@ __device__ __forceinline__ int segment_locate(const int* pref, int seg_cap, int 
     return seg * seg_cap + (gi - pref[seg]);
 }
 
-struct FilterShared {
+template <int LCAND, int WSLOTS>
+struct FilterSharedT {
     float tile[KF_CELLS_PER_BLOCK][9][10];  // per cell: x-pass sums, source row q, output column i
-    __attribute__((aligned(16))) float wts[KF_CELLS_PER_BLOCK][72];  // per border cell: the weights of the pass at hand
-    int2 cand[KF_LCAND];
+    __attribute__((aligned(16))) float wts[WSLOTS][72];  // per border cell in flight: the weights of the pass at hand
+    int2 cand[LCAND];
     int n_cand;
     int base;
 };
+typedef FilterSharedT<KF_LCAND, KF_CELLS_PER_BLOCK> FilterShared;
+// The workgroup of one small plane: a handful of candidates.
+#ifndef KF_LCAND_PLANE
+#define KF_LCAND_PLANE 128
+#endif
+#ifndef KF_PLANE_WSLOTS
+#define KF_PLANE_WSLOTS KF_CELLS_PER_BLOCK
+#endif
+typedef FilterSharedT<KF_LCAND_PLANE, KF_PLANE_WSLOTS> PlaneFilterShared;
 
 // One cell of the list, decoded, with the nine source values of this lane's row.
 struct CellWork {
@@ -689,6 +699,292 @@ k_cell_filter(CellFilterArgs a) {
             a.cand[(size_t)seg * a.cand_seg_cap + idx] = sh.cand[i];
         else
             atomicOr(a.cand_count + sh.cand[i].x, KF_OVERFLOW);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Small maps: active cells and candidate filter of a plane in one launch.  The workgroup that
+// has staged a plane in LDS and marked its active cells (as k_cells does) keeps the list in LDS
+// and filters those cells itself, reading their 9 x 9 source windows from the staged plane: no
+// cell list in memory, no second look at the map, one launch fewer.  Same arithmetic as
+// k_cell_filter, so the same candidates.
+// ---------------------------------------------------------------------------------
+struct CellsFilterArgs {
+    CellArgs c;
+    CellFilterArgs f;
+};
+
+// The cells of one kind in the workgroup's LDS list `list` (n of them): six per wavefront pass,
+// ten lanes per cell, windows from the plane `P` ([h][w], signed values).
+template <bool REG>
+__device__ __forceinline__ void filter_cells_lds(const CellFilterArgs& a, PlaneFilterShared& sh, const float* P, const int* list,
+                                                 int n, int list_step, int plane, float thr_lo, float e2, int lane) {
+    const int wv = threadIdx.x >> 6;
+    constexpr bool one_wave = KF_PLANE_WSLOTS == KF_CELLS_PER_WAVE;
+    if (!REG && one_wave && wv != 0) return;
+    const int cs = lane / 10, r = lane - cs * 10;
+    const bool lane_ok = cs < KF_CELLS_PER_WAVE;
+    const int slot = wv * KF_CELLS_PER_WAVE + (lane_ok ? cs : 0);
+    const int H = a.H, W = a.W, h = a.h, w = a.w;
+    float* wl = &sh.wts[one_wave ? (lane_ok ? cs : 0) : slot][0];
+    for (int base = wv * KF_CELLS_PER_WAVE; base < n; base += (!REG && one_wave) ? KF_CELLS_PER_WAVE : KF_CELLS_PER_BLOCK) {
+        const int ci = base + cs;
+        const bool act = lane_ok && ci < n;
+        int cy = 0, cx = 0;
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = 0.f;
+        if (act) {
+            const int e = list[ci * list_step];
+            cy = (e >> 7) & 127;
+            cx = e & 127;
+            if (r < 9) {
+                if (REG) {  // the 9 x 9 source window of a cell with interior weights lies inside the map
+                    const float* p = P + (cy - 4 + r) * w + (cx - 4);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) v[k] = p[k];
+                } else {
+                    const float* row = P + pd_clampi(cy - 4 + r, 0, h - 1) * w;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) v[k] = row[pd_clampi(cx - 4 + k, 0, w - 1)];
+                }
+            }
+        }
+        if (!REG) {
+            if (act && r < 9) {
+                const float4* kq = (const float4*)(a.cx + (size_t)cx * 72);
+                ((float4*)wl)[2 * r] = kq[2 * r];
+                ((float4*)wl)[2 * r + 1] = kq[2 * r + 1];
+            }
+            pd_wave_sync();
+        }
+        // x pass: lane r < 9 owns source row y-4+r and forms the ten column sums
+        if (act && r < 9) {
+            float* out = &sh.tile[slot][r][0];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const ConstF* kp = fresh_pointer(c_kf_interior);
+#pragma unroll
+                for (int i = 5 * half; i < 5 * half + 5; ++i) {
+                    const int p0 = i == 0 ? 0 : (i == 9 ? 2 : 1);
+                    if (!REG) asm volatile("" ::: "memory");  // keeps the weight reads of later sums out of registers
+                    float s = (REG ? kp[7 * i] : wl[7 * i]) * v[p0];
+#pragma unroll
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * i + p] : wl[7 * i + p], v[p0 + p], s);
+                    out[i] = s;
+                }
+            }
+        }
+        pd_wave_sync();  // the tile and the weights are private to this wavefront
+        if (!REG) {
+            if (act && r < 9) {
+                const float4* kq = (const float4*)(a.cy + (size_t)cy * 72);
+                ((float4*)wl)[2 * r] = kq[2 * r];
+                ((float4*)wl)[2 * r + 1] = kq[2 * r + 1];
+            }
+            pd_wave_sync();
+        }
+        // y pass: lane r owns output column 8x-1+r and forms its ten row sums
+        float S[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) S[j] = 0.f;
+        if (act) {
+            float t[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) t[q] = sh.tile[slot][q][r];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const ConstF* kp = fresh_pointer(c_kf_interior);
+#pragma unroll
+                for (int j = 5 * half; j < 5 * half + 5; ++j) {
+                    const int p0 = j == 0 ? 0 : (j == 9 ? 2 : 1);
+                    if (!REG) asm volatile("" ::: "memory");
+                    float s = (REG ? kp[7 * j] : wl[7 * j]) * t[p0];
+#pragma unroll
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * j + p] : wl[7 * j + p], t[p0 + p], s);
+                    S[j] = s;
+                }
+            }
+        }
+        pd_wave_sync();
+        // tolerant NMS of the cell's own 8 x 8 pixels (rows j = 1..8 of lanes r = 1..8);
+        // sums of outputs outside the map are zero, like the reference's zero border
+        const int X = 8 * cx - 1 + r;
+        const bool own = act && r >= 1 && r <= 8 && X < W;
+        unsigned hits = 0;
+#pragma unroll
+        for (int j = 1; j <= 8; ++j) {
+            const float c = S[j];
+            const float left = pd_lane_prev(c), right = pd_lane_next(c);
+            const float ce = c + e2;
+            const float m4 = fmaxf(fmaxf(S[j - 1], S[j + 1]), fmaxf(left, right));
+            hits |= (c > thr_lo && ce >= m4) ? (1u << j) : 0u;
+        }
+        if (!own) hits = 0;
+        if (hits) {  // rare
+#pragma unroll
+            for (int j = 1; j <= 8; ++j) {
+                const int Y = 8 * cy - 1 + j;
+                if (((hits >> j) & 1u) && Y < H) {
+                    atomicAdd(a.cand_count + plane, 1);
+                    const int pos = atomicAdd(&sh.n_cand, 1);
+                    if (pos < KF_LCAND_PLANE)
+                        sh.cand[pos] = make_int2(plane, (Y << 16) | X);
+                    else
+                        atomicOr(a.cand_count + plane, KF_OVERFLOW);  // no room: leave the plane to the exact kernel
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_cells_filter(CellsFilterArgs args) {
+    extern __shared__ __align__(16) float lds[];
+    __shared__ PlaneFilterShared sh;
+    __shared__ float s_red[4];
+    __shared__ int s_cnt[4][2];
+    const CellArgs& a = args.c;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per_xcd = gridDim.x / 8;
+    const int plane = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // the 18 planes of an image on one XCD
+    if (plane >= a.n_planes) return;
+    const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
+    const int h = a.h, w = a.w;
+    const int hc = a.hc, wc = a.wc;
+    const int bands = 256 / wc;
+    const int rows_per = (hc + bands - 1) / bands;  // <= 32
+    const int x = tid % wc, band = tid / wc;
+    const int ya = min(hc, band * rows_per), yb = band < bands ? min(hc, ya + rows_per) : ya;
+    float* P = lds;                    // [h][w] the plane
+    int* list = (int*)(lds + h * w);   // [hc * wc] interior-weight cells from the front, the others from the back
+    if (tid == 0) sh.n_cand = 0;
+    // ---- the plane to LDS, its maximum, its planar copy
+    const float* pix = a.nhwc + (size_t)b * h * w * PD_CH_HEAT + part;
+    float* copy = a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w;
+    float m = 0.f;
+    for (int i0 = 0; i0 < h * w; i0 += 256 * 9) {
+        float t[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = i0 + k * 256 + tid;
+            t[k] = i < h * w ? pix[(size_t)i * PD_CH_HEAT] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = i0 + k * 256 + tid;
+            if (i < h * w) {
+                P[i] = t[k];
+                m = fmaxf(m, fabsf(t[k]));
+                copy[i] = t[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if (lane == 0) s_red[wv] = m;
+    __syncthreads();
+    float thr_lo = 0.f, e2 = 0.f;
+    if (lane == 0) filter_slack(a.thr, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), &thr_lo, &e2);
+    thr_lo = __shfl(thr_lo, 0);
+    e2 = __shfl(e2, 0);
+    // ---- the bound U of every cell of the thread's band (as in k_cells)
+    unsigned m_reg = 0u, m_edge = 0u;
+    if (yb > ya) {
+        float kx[7];
+        int cx[7];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            kx[p] = a.bx[8 * x + p];
+            cx[p] = pd_clampi(x - 3 + p, 0, w - 1);
+        }
+        const int regx = a.regx[x];
+        float win[7];
+        win[0] = 0.f;
+#pragma unroll
+        for (int q = 1; q < 7; ++q) {
+            const float* row = P + pd_clampi(ya - 4 + q, 0, h - 1) * w;
+            float v = kx[0] * fabsf(row[cx[0]]);
+#pragma unroll
+            for (int p = 1; p < 7; ++p) v = fmaf(kx[p], fabsf(row[cx[p]]), v);
+            win[q] = v;
+        }
+        for (int y = ya; y < yb; ++y) {
+#pragma unroll
+            for (int p = 0; p < 6; ++p) win[p] = win[p + 1];
+            {
+                const float* row = P + min(y + 3, h - 1) * w;
+                float v = kx[0] * fabsf(row[cx[0]]);
+#pragma unroll
+                for (int p = 1; p < 7; ++p) v = fmaf(kx[p], fabsf(row[cx[p]]), v);
+                win[6] = v;
+            }
+            const float4 ka = *(const float4*)(a.by + 8 * y), kb = *(const float4*)(a.by + 8 * y + 4);
+            float u = ka.x * win[0];
+            u = fmaf(ka.y, win[1], u);
+            u = fmaf(ka.z, win[2], u);
+            u = fmaf(ka.w, win[3], u);
+            u = fmaf(kb.x, win[4], u);
+            u = fmaf(kb.y, win[5], u);
+            u = fmaf(kb.z, win[6], u);
+            if (u * 1.00001f >= thr_lo) {
+                if (a.regy[y] & regx)
+                    m_reg |= 1u << (y - ya);
+                else
+                    m_edge |= 1u << (y - ya);
+            }
+        }
+    }
+    // ---- the workgroup's cell list in LDS
+    const int c_r = __builtin_popcount(m_reg), c_e = __builtin_popcount(m_edge);
+    int p_r = c_r, p_e = c_e;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o_r = __shfl_up(p_r, d), o_e = __shfl_up(p_e, d);
+        if (lane >= d) {
+            p_r += o_r;
+            p_e += o_e;
+        }
+    }
+    if (lane == 63) {
+        s_cnt[wv][0] = p_r;
+        s_cnt[wv][1] = p_e;
+    }
+    __syncthreads();
+    int at_r = p_r - c_r, at_e = p_e - c_e;
+    for (int q = 0; q < wv; ++q) {
+        at_r += s_cnt[q][0];
+        at_e += s_cnt[q][1];
+    }
+    const int n_reg = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+    const int n_edge = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+    const int n_cells = hc * wc;
+    while (m_reg) {
+        const int bit = __builtin_ctz(m_reg);
+        m_reg &= m_reg - 1u;
+        list[at_r++] = ((ya + bit) << 7) | x;
+    }
+    while (m_edge) {
+        const int bit = __builtin_ctz(m_edge);
+        m_edge &= m_edge - 1u;
+        list[n_cells - 1 - (at_e++)] = ((ya + bit) << 7) | x;
+    }
+    __syncthreads();
+    // ---- the candidate filter on those cells
+    filter_cells_lds<true>(args.f, sh, P, list, n_reg, 1, plane, thr_lo, e2, lane);
+    filter_cells_lds<false>(args.f, sh, P, list + n_cells - 1, n_edge, -1, plane, thr_lo, e2, lane);
+    __syncthreads();
+    const int seg = plane % KF_NSEG;
+    const int nc = min(sh.n_cand, KF_LCAND_PLANE);
+    if (nc == 0) return;
+    if (tid == 0) sh.base = atomicAdd(args.f.cand_n + seg, nc);
+    __syncthreads();
+    for (int i = tid; i < nc; i += 256) {
+        const int idx = sh.base + i;
+        if (idx < args.f.cand_seg_cap)
+            args.f.cand[(size_t)seg * args.f.cand_seg_cap + idx] = sh.cand[i];
+        else
+            atomicOr(args.f.cand_count + sh.cand[i].x, KF_OVERFLOW);
     }
 }
 
@@ -942,6 +1238,21 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     f.CK = CK;
 
     // cand_count and the list counters were cleared together with raw_count
+    static const bool split_cells = [] {
+        const char* v = getenv("PD_SPLIT_CELLS");
+        return v && *v && *v != '0';
+    }();  // comparison runs: the two launches also for small maps
+    const size_t fused_lds = sizeof(float) * (size_t)h * w + sizeof(int) * (size_t)hc * wc;
+    if (gather && !split_cells && 256 / wc >= 1 && (hc + 256 / wc - 1) / (256 / wc) <= 32 && hc <= h && wc <= w && hc < 128 && wc < 128 &&
+        fused_lds <= 40 * 1024) {
+        CellsFilterArgs cf;
+        cf.c = c;
+        cf.f = f;
+        pd_prof_begin(ctx, PD_STAGE_FILTER);
+        hipLaunchKernelGGL(k_cells_filter, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(256), fused_lds, ctx->stream, cf);
+        pd_prof_end(ctx);
+        PD_HIP(ctx, hipGetLastError());
+    } else {
     if (!gather) {
         pd_prof_begin(ctx, PD_STAGE_PLANAR);
         hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
@@ -967,6 +1278,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     hipLaunchKernelGGL(k_cell_filter, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, f);
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
+    }
 
     VerifyArgs v;
     v.full = nullptr;
