@@ -450,19 +450,23 @@ def run_single(env):
             roofline['wasted_traffic_ratio'] = step_traffic / must_bytes
         if roof_n:
             f_s = roof_ms / roof_n * 1e-3
+            # the kernel of the filter stage: maps of up to 4096 pixels take the fused form
+            # (active cells + filter of a plane in one launch), larger ones the cell filter alone
+            fused_small = n <= 4096 and os.environ.get('PD_SPLIT_CELLS', '0') in ('', '0')
+            roof_kernel = 'k_cells_filter' if fused_small else 'k_cell_filter'
             kt = None
             if pmc and pmc.get('kernels'):
                 for kname, kv in pmc['kernels'].items():
-                    if kname.startswith('k_cell_filter'):
+                    if kname.split('(')[0] == roof_kernel:
                         kt = kv['hbm_bytes']
-            roofline['k_cell_filter'] = {
+            roofline[roof_kernel] = {
                 'avg_launch_ms': f_s * 1e3, 'launches': roof_n,
                 'measured': 'HIP event pair around the kernel in every decode of the timed region',
                 'traffic': kt, 'achieved': (kt / f_s / 1e9) if kt else None,
                 'frac': (kt / f_s / 1e9 / HBM_PEAK_GBS) if kt else None,
                 'bound': 'valu issue + latency (profiles/*sq_counters*)'}
             if alone and alone[1]:
-                roofline['k_cell_filter']['one_context_avg_launch_ms'] = alone[0] / alone[1]
+                roofline[roof_kernel]['one_context_avg_launch_ms'] = alone[0] / alone[1]
         if dense_ms:
             dense_bytes = B * (72.0 * n + 288.0 * N)
             peak_stage_ms = sum(prof[k][0] / prof[k][1] for k in ('planar', 'cells', 'filter', 'verify', 'smooth_nms')

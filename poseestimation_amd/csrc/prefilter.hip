@@ -975,6 +975,8 @@ k_cells_filter(CellsFilterArgs args) {
     filter_cells_lds<false>(args.f, sh, P, list + n_cells - 1, n_edge, -1, plane, thr_lo, e2, lane);
     __syncthreads();
     const int seg = plane % KF_NSEG;
+    if (tid == 64 && n_reg) atomicAdd(a.n_reg + seg, n_reg);  // the list lengths, for the statistics only
+    if (tid == 128 && n_edge) atomicAdd(a.n_edge + seg, n_edge);
     const int nc = min(sh.n_cand, KF_LCAND_PLANE);
     if (nc == 0) return;
     if (tid == 0) sh.base = atomicAdd(args.f.cand_n + seg, nc);

@@ -40,6 +40,10 @@ def test_batch_64_at_368_every_image_matches_the_oracle(mode):
     eng = DecodeEngine(max_batch=B, max_h=H, max_w=W, mode=mode, max_peaks_per_part=128, max_persons=128,
                        max_pairs_per_image=40000)
     res = eng.decode_batch(heat, paf)
+    stats = eng.ctx.filter_stats()
+    assert stats['planes_exact'] == 0 and stats['candidates'] >= res.packed['peaks'].shape[0]
+    # a peak stage that visits a part of the map: some cells of both kinds, far from all of them
+    assert 0 < stats['cells_border'] < stats['cells_interior'] < B * 19 * 23 * 23 // 2
     again = eng.decode_batch(heat, paf)
     for key in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
         assert np.array_equal(res.packed[key], again.packed[key]), key       # deterministic
