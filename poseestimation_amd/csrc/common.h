@@ -312,6 +312,21 @@ __device__ __forceinline__ float pd_lane_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
 
+// max(prev(v), next(v), a, b), prev / next as above: the two shifts ride in the data path of two
+// maximum instructions (three instructions where moves, their zeroed destinations and the
+// maxima take eight).  A shifted operand must not have been written by the two instructions
+// before, which the leading no-op sees to.
+__device__ __forceinline__ float pd_max_lane_neighbours(float v, float a, float b) {
+    float p, q;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_max_f32_dpp %1, %2, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_max_f32 %0, %0, %1"
+        : "=&v"(p), "=&v"(q)
+        : "v"(v), "v"(a), "v"(b));
+    return p;
+}
+
 // scipy mode='reflect' index (d c b a | a b c d | d c b a) for any offset.
 __device__ __forceinline__ int pd_reflect(int i, int n) {
     if (i >= 0 && i < n) return i;

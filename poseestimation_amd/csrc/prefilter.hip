@@ -643,9 +643,8 @@ __device__ __forceinline__ void filter_cells(const CellFilterArgs& a, FilterShar
 #pragma unroll
         for (int j = 1; j <= 8; ++j) {
             const float c = S[j];
-            const float left = pd_lane_prev(c), right = pd_lane_next(c);
             const float ce = c + cur.e2;
-            const float m4 = fmaxf(fmaxf(S[j - 1], S[j + 1]), fmaxf(left, right));
+            const float m4 = pd_max_lane_neighbours(c, S[j - 1], S[j + 1]);
             hits |= (c > cur.thr_lo && ce >= m4) ? (1u << j) : 0u;
         }
         if (!own) hits = 0;
@@ -815,9 +814,8 @@ __device__ __forceinline__ void filter_cells_lds(const CellFilterArgs& a, PlaneF
 #pragma unroll
         for (int j = 1; j <= 8; ++j) {
             const float c = S[j];
-            const float left = pd_lane_prev(c), right = pd_lane_next(c);
             const float ce = c + e2;
-            const float m4 = fmaxf(fmaxf(S[j - 1], S[j + 1]), fmaxf(left, right));
+            const float m4 = pd_max_lane_neighbours(c, S[j - 1], S[j + 1]);
             hits |= (c > thr_lo && ce >= m4) ? (1u << j) : 0u;
         }
         if (!own) hits = 0;
