@@ -198,7 +198,7 @@ enum {
     PD_STAGE_FILTER = 7,     /* float32 candidate filter (active cells, or every pixel of full-resolution maps) */
     PD_STAGE_VERIFY = 8,     /* exact float64 verification of the candidates */
     PD_STAGE_PLANAR = 9,     /* (h, w, 19) -> planar copy of the heatmaps (maps beyond 4096 pixels only) */
-    PD_STAGE_CELLS = 10,     /* active-cell scan at network resolution */
+    PD_STAGE_CELLS = 10,     /* active-cell scan at network resolution (maps beyond 4096 pixels; smaller ones: inside PD_STAGE_FILTER) */
     PD_N_STAGES = 11
 };
 int pd_profile(pd_ctx* ctx, int enable);
