@@ -858,23 +858,42 @@ k_cells_filter(CellsFilterArgs args) {
     int* list = (int*)(lds + h * w);   // [hc * wc] interior-weight cells from the front, the others from the back
     if (tid == 0) sh.n_cand = 0;
     // ---- the plane to LDS, its maximum, its planar copy
-    const float* pix = a.nhwc + (size_t)b * h * w * PD_CH_HEAT + part;
     float* copy = a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w;
     float m = 0.f;
-    for (int i0 = 0; i0 < h * w; i0 += 256 * 9) {
-        float t[9];
+    if (a.nhwc) {  // from the network's interleaved output, leaving the planar copy behind
+        const float* pix = a.nhwc + (size_t)b * h * w * PD_CH_HEAT + part;
+        for (int i0 = 0; i0 < h * w; i0 += 256 * 9) {
+            float t[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int i = i0 + k * 256 + tid;
-            t[k] = i < h * w ? pix[(size_t)i * PD_CH_HEAT] : 0.f;
+            for (int k = 0; k < 9; ++k) {
+                const int i = i0 + k * 256 + tid;
+                t[k] = i < h * w ? pix[(size_t)i * PD_CH_HEAT] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int i = i0 + k * 256 + tid;
+                if (i < h * w) {
+                    P[i] = t[k];
+                    m = fmaxf(m, fabsf(t[k]));
+                    copy[i] = t[k];
+                }
+            }
         }
+    } else {  // from the planar copy made beforehand
+        for (int i0 = 0; i0 < h * w; i0 += 256 * 9) {
+            float t[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int i = i0 + k * 256 + tid;
-            if (i < h * w) {
-                P[i] = t[k];
-                m = fmaxf(m, fabsf(t[k]));
-                copy[i] = t[k];
+            for (int k = 0; k < 9; ++k) {
+                const int i = i0 + k * 256 + tid;
+                t[k] = i < h * w ? copy[i] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int i = i0 + k * 256 + tid;
+                if (i < h * w) {
+                    P[i] = t[k];
+                    m = fmaxf(m, fabsf(t[k]));
+                }
             }
         }
     }
@@ -1209,7 +1228,12 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     // copy behind (one launch fewer; the decode of a small batch is bound by launch latency).
     // Large maps: the strided reads would pull every cache line through the L2 eighteen times,
     // so the copy is made first, by a kernel that reads and writes coalesced.
-    const bool gather = (size_t)h * w <= 4096;
+    static const bool planar_first = [] {
+        const char* v = getenv("PD_PLANAR_FIRST");
+        return v && *v && *v != '0';
+    }();
+    const bool small_map = (size_t)h * w <= 4096;
+    const bool gather = small_map && !planar_first;
     c.nhwc = gather ? ctx->lo_heat : nullptr;
     c.planar_out = ctx->heat_planar;
     c.thr = thr;
@@ -1243,11 +1267,17 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         return v && *v && *v != '0';
     }();  // comparison runs: the two launches also for small maps
     const size_t fused_lds = sizeof(float) * (size_t)h * w + sizeof(int) * (size_t)hc * wc;
-    if (gather && !split_cells && 256 / wc >= 1 && (hc + 256 / wc - 1) / (256 / wc) <= 32 && hc <= h && wc <= w && hc < 128 && wc < 128 &&
+    if (small_map && !split_cells && 256 / wc >= 1 && (hc + 256 / wc - 1) / (256 / wc) <= 32 && hc <= h && wc <= w && hc < 128 && wc < 128 &&
         fused_lds <= 40 * 1024) {
         CellsFilterArgs cf;
         cf.c = c;
         cf.f = f;
+        if (!gather) {
+            pd_prof_begin(ctx, PD_STAGE_PLANAR);
+            hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
+                               h * w, ctx->heat_planar, (unsigned int*)nullptr);
+            pd_prof_end(ctx);
+        }
         pd_prof_begin(ctx, PD_STAGE_FILTER);
         hipLaunchKernelGGL(k_cells_filter, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(256), fused_lds, ctx->stream, cf);
         pd_prof_end(ctx);
