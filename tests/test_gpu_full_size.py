@@ -350,3 +350,47 @@ def test_matching_beyond_the_sort_list_takes_the_arg_max_form(cap):
         _assert_image(res, b, want, 'D')
     assert n_conn > 3 * cap or cap > 4      # with cap 4 every busy limb overflows the list
     eng.close()
+
+
+_SWITCH_SCRIPT = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from poseestimation_amd import synth
+from poseestimation_amd.predict_decode import DecodeEngine
+out = hashlib.sha256()
+for (B, H, W, people) in ((6, 368, 368, (1, 8)), (3, 236, 323, (1, 4)), (2, 656, 656, 12)):
+    heat, paf = synth.batch(B, H, W, people, seed0=4200, paf_order='xy')
+    eng = DecodeEngine(max_batch=B, max_h=H, max_w=W, mode='D', max_peaks_per_part=128, max_persons=128,
+                       max_pairs_per_image=40000)
+    for _ in range(4):      # eager, recording, replays
+        res = eng.decode_batch(heat, paf, out_hw=(H, W))
+    for key in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
+        out.update(np.ascontiguousarray(res.packed[key]).tobytes())
+    st = eng.ctx.filter_stats()
+    out.update(repr(sorted(st.items())).encode())
+    eng.close()
+print('DIGEST', out.hexdigest())
+'''
+
+
+def test_comparison_switches_leave_the_results_alone():
+    """The environment switches that keep kernels apart (or put the layout kernel in front) are
+    read once per process: a child process per setting decodes the same batches; packed results
+    and filter statistics must be the same bytes as with no switch set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for name in ('', 'PD_SPLIT_CELLS', 'PD_PLANAR_FIRST', 'PD_SEPARATE_PACK', 'PD_SEPARATE_SORT'):
+        env = {k: v for k, v in os.environ.items() if not k.startswith('PD_')}
+        if name:
+            env[name] = '1'
+        p = subprocess.run([sys.executable, '-c', _SWITCH_SCRIPT % root], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=100)
+        assert p.returncode == 0, p.stdout[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith('DIGEST ')]
+        assert len(lines) == 1, p.stdout[-2000:]
+        digests[name or 'default'] = lines[0]
+    assert len(set(digests.values())) == 1, digests
