@@ -262,7 +262,10 @@ def run_single(env):
             nbuf = graph_friendly_buffers(NBUF, n)
             pending, last = [], None
             for i in range(ndecodes):
-                e = pool[i % n]
+                # context and input buffer both follow the count of decodes issued since the start,
+                # so a context meets the same few buffers in every call of run() and replays the
+                # launch sequences it has recorded for them, whatever the lengths of earlier runs
+                e = pool[counter[0] % n]
                 if len(pending) == n:
                     pe, pk = pending.pop(0)
                     last = (pe.ctx.fetch(), pk)     # waits for that stream; results now on the host
@@ -349,6 +352,16 @@ def run_single(env):
     if os.environ.get('PD_BENCH_TIMERS') == '1' and host_t[4]:
         sys.stderr.write('host us per round: finish %.1f submit %.1f flush %.1f start %.1f (rounds %d)\n'
                          % tuple([x / host_t[4] * 1e6 for x in host_t[:4]] + [host_t[4]]))
+    if os.environ.get('PD_BENCH_REGIONS'):
+        # diagnostic: further timed regions of the given step counts, each bracketed like the
+        # first, to see how the length of a region changes the rate it reports
+        for k in [int(x) for x in os.environ['PD_BENCH_REGIONS'].split(',')]:
+            barrier()
+            ta = time.perf_counter()
+            run(k * per_step)
+            barrier()
+            tb = time.perf_counter() - ta
+            sys.stderr.write('region of %d steps: %.1f us per step, %.0f images/s\n' % (k, tb / k * 1e6, B * per_step * k / tb))
     roof_ms, roof_n = 0.0, 0
     for e in engs:
         v = e.ctx.profile_read()[ROOF_STAGE]
