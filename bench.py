@@ -140,7 +140,7 @@ def main():
             os.close(saved_stdout)
 
     env = dict(args=args, wl=wl, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist, rounds=rounds,
-               torch=torch, dist=dist)
+               torch=torch, dist=dist, token=torch.zeros(1, device='cuda') if use_dist else None)
     out = run_multiscale(env) if multiscale else run_single(env)
     parity_failed = False
     if rank == 0:
@@ -160,7 +160,10 @@ def make_barrier(env):
     def barrier():
         torch.cuda.synchronize()         # device-wide: covers the contexts' own streams
         if env['use_dist']:
-            dist.barrier()
+            if os.environ.get('PD_BENCH_BARRIER') == 'allreduce':
+                dist.all_reduce(env['token'])
+            elif os.environ.get('PD_BENCH_BARRIER') != 'none':
+                dist.barrier()
         torch.cuda.synchronize()
     return barrier
 
@@ -247,7 +250,7 @@ def run_single(env):
         for e in engs:      # everything a rank produces leaves through the gather
             e.ctx.set_host_results(False)
 
-    host_t = [0.0, 0.0, 0.0, 0.0, 0]   # finish, submit, flush, start, rounds
+    host_t = [0.0, 0.0, 0.0, 0.0, 0, 0.0, 0]   # finish, submit, flush, start, rounds, longest start, its round
     counter = [0]                      # decodes issued so far: picks the input buffer
 
     def run(ndecodes, pool=None):
@@ -311,6 +314,8 @@ def run_single(env):
             host_t[1] += tc - tb
             host_t[2] += td - tc
             host_t[3] += te - td
+            if te - td > host_t[5]:
+                host_t[5], host_t[6] = te - td, r
             host_t[4] += 1
             pending[s] = bufs
             done += k
@@ -340,11 +345,23 @@ def run_single(env):
     # buffer and skeleton slice); with a process group, the first gathers also set up RCCL's
     # channels and the launcher threads
     run(3 * max(NBUF, len(engs) * GATHER_DEPTH * 2) if gather is None else 8 * len(engs) * GATHER_DEPTH)
+    if use_dist:
+        # One of the first twenty or so gathers of a process group holds the issuing thread for
+        # 4-5 ms, once (measured with one rank: it fell into a 20-step region behind 9 rounds of
+        # warm-up and into the next region behind 11; no later round did it again).  The warm-up
+        # goes on until 24 rounds in a row have issued their gather in under a millisecond.
+        quiet, total = 0, 0
+        while quiet < 24 and total < 400:
+            host_t[:] = [0.0, 0.0, 0.0, 0.0, 0, 0.0, 0]
+            run(4 * len(engs) * GATHER_DEPTH)
+            # (the ranks must agree on the number of gathers: the slowest rank's figure decides)
+            quiet = quiet + 4 if max_over_ranks(env, host_t[5]) < 1e-3 else 0
+            total += 4
     run(args.warmup * per_step)
     for e in engs:
         e.ctx.profile_read()
     barrier()
-    host_t[:] = [0.0, 0.0, 0.0, 0.0, 0]
+    host_t[:] = [0.0, 0.0, 0.0, 0.0, 0, 0.0, 0]
     t0 = time.perf_counter()
     last = run(args.steps * per_step)
     barrier()
@@ -357,11 +374,15 @@ def run_single(env):
         # first, to see how the length of a region changes the rate it reports
         for k in [int(x) for x in os.environ['PD_BENCH_REGIONS'].split(',')]:
             barrier()
+            host_t[:] = [0.0, 0.0, 0.0, 0.0, 0, 0.0, 0]
             ta = time.perf_counter()
             run(k * per_step)
+            tc = time.perf_counter() - ta
             barrier()
             tb = time.perf_counter() - ta
-            sys.stderr.write('region of %d steps: %.1f us per step, %.0f images/s\n' % (k, tb / k * 1e6, B * per_step * k / tb))
+            sys.stderr.write('region of %d steps: %.1f us per step, %.0f images/s (run %.0f us; host finish %.0f submit %.0f flush %.0f start %.0f us, longest %.0f us in round %d)\n'
+                             % (k, tb / k * 1e6, B * per_step * k / tb, tc * 1e6, host_t[0] * 1e6, host_t[1] * 1e6, host_t[2] * 1e6, host_t[3] * 1e6,
+                                host_t[5] * 1e6, host_t[6]))
     roof_ms, roof_n = 0.0, 0
     for e in engs:
         v = e.ctx.profile_read()[ROOF_STAGE]
