@@ -144,6 +144,10 @@ class SkeletonGather:
                 self.recv = [torch.zeros(self.world * row, dtype=torch.uint8, device=rdev) for _ in range(sets)]
             if self.on_gpu:
                 self.host = [torch.zeros(self.world * row, dtype=torch.uint8).pin_memory() for _ in range(sets)]
+        # the root's receive views, one list per set, made once (not per round)
+        self.recv_views = None
+        if self.recv is not None:
+            self.recv_views = [list(r.view(self.world, -1).unbind(0)) for r in self.recv]
         self.work = [None] * sets
         self.streams = self.copy_stream = None
         if self.on_gpu:
@@ -176,9 +180,7 @@ class SkeletonGather:
         else:
             self.stage[s].copy_(src)     # the caller has waited for the contexts
             src = self.stage[s]
-        gl = None
-        if self.rank == self.dst:
-            gl = list(self.recv[s].view(self.world, -1).unbind(0))
+        gl = self.recv_views[s] if self.rank == self.dst else None
         self.work[s] = self.dist.gather(src, gather_list=gl, dst=self.dst, group=self.group, async_op=True)
         if self.on_gpu:
             # wait() orders a stream behind the collective without blocking the host; the copy to
