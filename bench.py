@@ -686,6 +686,23 @@ def run_multiscale(env):
         if traffic:
             roofline['traffic_frac'] = traffic / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             roofline['wasted_traffic_ratio'] = traffic / must
+        if 'filter' in stage and stage['filter'][1]:
+            # the peak stage behind the resize: one float32 streaming pass over the 18 float64
+            # heat planes of every image (upsampled maps are the input here, so every pixel is read)
+            f_ms = stage['filter'][0] / stage['filter'][1]
+            f_must = B * 18.0 * N * 8
+            f_traffic = None
+            if pmc and pmc.get('kernels'):
+                for kname, kv in pmc['kernels'].items():
+                    if kname.split('(')[0].split('<')[0] == 'k_full_filter':
+                        f_traffic = kv['hbm_bytes']
+            roofline['k_full_filter'] = {
+                'bound': 'hbm', 'algorithmic_bytes_per_launch': f_must,
+                'bytes_counted': 'B * 18 * N * 8: the float64 averages of the 18 part planes read once (candidates written: negligible)',
+                'avg_launch_ms': f_ms, 'launches': stage['filter'][1],
+                'measured': 'HIP event pair around the kernel in every step of the timed region',
+                'achieved': f_must / (f_ms * 1e-3) / 1e9, 'frac': f_must / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'traffic': f_traffic}
         out = {
             'metric': 'decoded images/sec (heatmap+PAF->skeletons) at %dx%d' % (H, W),
             'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
