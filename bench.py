@@ -55,6 +55,54 @@ def graph_friendly_buffers(nbuf, n_ctx, slots=6):
     return 1
 
 
+def _cpu_image(job):
+    """Worker of cpu_all_cores: one image through the CPU restatement; returns its person count."""
+    heat, paf, mode = job
+    from oracle import decode_ref as ref
+    hf = ref.resize_cubic(heat, fx=8, fy=8).astype(np.float64)
+    pf = ref.resize_cubic(paf, fx=8, fy=8).astype(np.float64)
+    peaks = ref.get_peaks(hf, 0.1, mode, use_scipy=True)
+    conns, special = ref.get_connections(peaks, pf, 0.05, mode)
+    return int(ref.multi_person_parse(peaks, conns, special, mode).shape[0])
+
+
+def cpu_all_cores(args, wl):
+    """The CPU restatement on all the cores this job has (images are independent: one process
+    per core, one image at a time each).  Runs before the process has touched the GPU, because
+    its workers are forked.  A reported figure beside `cpu_baseline`; None if anything goes wrong."""
+    import multiprocessing as mp
+    pool = None
+    try:
+        from oracle import decode_ref   # noqa: F401  (loaded before the fork)
+        from poseestimation_amd import synth
+        try:
+            share = len(os.sched_getaffinity(0))
+        except AttributeError:
+            share = os.cpu_count() or 1
+        # a GPU box grants 16 cores of a much larger machine and says so through OMP_NUM_THREADS
+        workers = max(1, min(share, int(os.environ.get('OMP_NUM_THREADS', '16') or 16), 16))
+        per = 2
+        n = workers * per
+        heat, paf = synth.batch(min(n, wl['B']), wl['H'], wl['W'], wl['people'], seed0=0,
+                                paf_order='xy' if args.mode == 'D' else 'yx')
+        jobs = [(heat[i % len(heat)], paf[i % len(heat)], args.mode) for i in range(n)]
+        pool = mp.get_context('fork').Pool(workers)
+        pool.map_async(_cpu_image, jobs[:workers], chunksize=1).get(timeout=120)   # every worker warm
+        t0 = time.perf_counter()
+        pool.map_async(_cpu_image, jobs, chunksize=1).get(timeout=240)
+        dt = time.perf_counter() - t0
+        return {'value': n / dt, 'unit': 'images/s', 'cores': workers, 'kind': 'port',
+                'sample': '%d images of the workload through oracle/decode_ref.py, %d single-threaded worker '
+                          'processes at once' % (n, workers)}
+    except Exception as exc:      # the figure is optional: never let it stop the bench
+        sys.stderr.write('cpu_all_cores skipped: %r\n' % (exc,))
+        return None
+    finally:
+        if pool is not None:
+            pool.terminate()
+            pool.join()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -111,6 +159,9 @@ def main():
         have_q = 4
     if args.hw_queues > have_q:
         os.environ['GPU_MAX_HW_QUEUES'] = str(args.hw_queues)
+    all_cores = None
+    if world == 1 and not use_dist and not multiscale and not args.no_cpu and not args.no_extras:
+        all_cores = cpu_all_cores(args, wl)     # before anything touches the GPU
     import torch
     import torch.distributed as dist
 
@@ -140,7 +191,7 @@ def main():
             os.close(saved_stdout)
 
     env = dict(args=args, wl=wl, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist, rounds=rounds,
-               torch=torch, dist=dist, token=torch.zeros(1, device='cuda') if use_dist else None)
+               torch=torch, dist=dist, all_cores=all_cores, token=torch.zeros(1, device='cuda') if use_dist else None)
     out = run_multiscale(env) if multiscale else run_single(env)
     parity_failed = False
     if rank == 0:
@@ -565,6 +616,8 @@ def run_single(env):
                                    'sample': '%d images of the same batch through oracle/decode_ref.py '
                                              '(numpy bicubic + scipy gaussian_filter + numpy decode), one thread; '
                                              'host has %d cpus' % (ncpu, os.cpu_count())}
+            if env.get('all_cores'):
+                out['cpu_baseline_all_cores'] = env['all_cores']
             out['parity_checked_images'] = ncpu
             out['parity_ok'] = bool(ok)
     for e in engs:
