@@ -160,7 +160,10 @@ def main():
     if args.hw_queues > have_q:
         os.environ['GPU_MAX_HW_QUEUES'] = str(args.hw_queues)
     all_cores = None
-    if world == 1 and not use_dist and not multiscale and not args.no_cpu and not args.no_extras:
+    # (not under a profiler: its preloaded library may have started the GPU runtime already,
+    # and a process in that state is not forked)
+    profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+    if world == 1 and not use_dist and not multiscale and not args.no_cpu and not args.no_extras and not profiled:
         all_cores = cpu_all_cores(args, wl)     # before anything touches the GPU
     import torch
     import torch.distributed as dist
