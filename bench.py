@@ -294,7 +294,9 @@ def run_single(env):
                                   share_stream_with=engs[i]) for i in range(n_ctx)]
     eng = engs[0]
     gather_cap = 1 << 18      # per rank and decode: header, count tables, peaks, person rows
-    while gather_cap < B * 4096:
+    # (about 0.45 KB per person and image: 18 peaks of 16 bytes, a person row of 160)
+    pmax = people if isinstance(people, int) else max(people)
+    while gather_cap < B * 4096 * ((pmax + 7) // 8):
         gather_cap <<= 1
 
     gather = gather1 = None
