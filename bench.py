@@ -660,7 +660,44 @@ def run_multiscale(env):
     hp = [t.data_ptr() for t in d_heats]
     pp = [t.data_ptr() for t in d_pafs]
 
+    # N > 1: a rank's skeletons (peaks and person rows) leave through its contexts' skeleton
+    # buffers and one gather per round of steps brings them to rank 0, as in the single-scale path
+    gather = None
+    if env['use_dist']:
+        from poseestimation_amd import sharding
+        gather_cap = 1 << 18
+        while gather_cap < B * 4096:
+            gather_cap <<= 1
+        gather = sharding.SkeletonGather([e.ctx for e in engs], gather_cap, depth=1)
+        for e in engs:
+            e.ctx.set_host_results(False)
+
     def run(nsteps):
+        if gather is not None:
+            n, r, done, last = len(engs), 0, 0, None
+            busy = [False, False]
+            while done < nsteps:
+                s = r % 2
+                if busy[s]:
+                    rows = gather.finish(s)
+                    if rows is not None:
+                        last = rows
+                k = min(n, nsteps - done)
+                for j in range(k):
+                    gather.point(s, j, j)
+                    engs[j].ctx.upsample_avg_device(hp, pp, sizes, crops, H, W, B)
+                    engs[j].ctx.decode_fullres(0.1, 0.05)
+                gather.start(s)
+                busy[s] = True
+                done += k
+                r += 1
+            for s in (r % 2, (r + 1) % 2):
+                if busy[s]:
+                    rows = gather.finish(s)
+                    if rows is not None:
+                        last = rows
+            # (rank 0) the images of all ranks, in image order
+            return None if last is None else sharding.SkeletonGather.results(last)[0]
         pending, last = [], None
         for i in range(nsteps):
             e = engs[i % len(engs)]
@@ -770,7 +807,8 @@ def run_multiscale(env):
                        'contexts_per_gpu': len(engs), 'scales': list(SCALES),
                        'inputs': 'device-resident network outputs of the four scales (%.0f MB per step; %d distinct '
                                  'scenes repeated to the batch)' % (B * 228.0 * n_sum / 1e6, NSCENE),
-                       'outputs': 'full packed results copied to the host every step'},
+                       'outputs': 'full packed results copied to the host every step' if gather is None else
+                                  'peaks and person rows of every rank gathered to rank 0 over RCCL, one gather per step'},
             'roofline': roofline,
             'stage_ms_per_step_timed_region': {k: v[0] / args.steps for k, v in stage.items() if v[1]},
         }

@@ -132,6 +132,44 @@ def test_four_scales_at_368():
     eng.close()
 
 
+def test_multiscale_skeletons_leave_through_the_gather_buffer():
+    """The multi-scale decode of a sharded job: with a skeleton buffer set, the decode of the
+    averaged maps writes peaks and person rows there (host results on, then off), and a round
+    of SkeletonGather(local=True) returns them: equal to the fetched results both times."""
+    from poseestimation_amd import sharding, synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    B, H, W = 5, 184, 184
+    scales = [0.5, 1.0, 2.0]
+    heats, pafs = [], []
+    for s in scales:
+        outs = [synth.scene(H, W, 1 + b % 4, 1200 + b, paf_order='xy', scale=s) for b in range(B)]
+        heats.append(np.stack([o[0] for o in outs]))
+        pafs.append(np.stack([o[1] for o in outs]))
+    pads = [(0, 0)] * 3
+    eng = DecodeEngine(B, H, W, mode='D')
+    want = eng.decode_multiscale(heats, pafs, pads, (H, W)).packed
+    assert want['person_count'].sum() > 0
+    g = sharding.SkeletonGather([eng.ctx], 1 << 16, depth=1, local=True)
+    for host_results in (True, False):
+        eng.ctx.set_host_results(host_results)
+        for s in (0, 1):
+            g.point(s, 0, 0)
+            if host_results:
+                got_host = eng.decode_multiscale(heats, pafs, pads, (H, W)).packed
+                assert np.array_equal(got_host['persons'], want['persons'])
+            else:
+                eng.upsample_average(heats, pafs, pads, (H, W))
+                eng.ctx.decode_fullres(0.1, 0.05)
+            g.start(s)
+        for s in (0, 1):
+            got = sharding.SkeletonGather.results(g.finish(s))[0]
+            for key in ('part_count', 'person_count', 'status', 'peaks', 'persons'):
+                assert np.array_equal(got[key], want[key]), (host_results, s, key)
+    eng.ctx.set_host_results(True)
+    eng.ctx.set_skeleton_buffer(None, 0)
+    eng.close()
+
+
 def test_config4_batch_128_four_scales():
     """BASELINE config 4 at its size on one GPU: 128 images x scales (0.5, 1, 1.5, 2) at 368^2
     through predict.py:49-72 (x8 bicubic, resize, average) and the decode.  A sample of images
