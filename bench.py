@@ -718,6 +718,8 @@ def run_multiscale(env):
     for e in engs:
         e.ctx.profile(stages=TIMED)
     run(2 * len(engs))
+    if gather is not None:
+        run(24)     # past the one slow gather among a process group's first twenty or so (see run_single)
     run(min(args.warmup, 4))
     for e in engs:
         e.ctx.profile_read()
