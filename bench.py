@@ -181,7 +181,9 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            if world > 1:
+            if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ:
+                # (a one-rank rehearsal under torch.distributed.run must use the launcher's store
+                # too: its workers connect to that store whatever address they are given)
                 dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
             else:
                 dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1,
