@@ -285,3 +285,26 @@ def test_render_lists_follow_visualize():
     import math
     assert ellipses.tolist() == [[25, 40, 25, 4, int(math.degrees(math.atan2(-40, -30))), 0],
                                  [11, 20, 1, 4, 180, 6]]
+
+
+def test_bench_pairs_a_context_with_few_buffers_whatever_the_run_lengths():
+    """bench.py picks the context and the input buffer of a decode by one count of decodes
+    issued since the start: whatever the lengths of the runs before it (priming, a warm-up of 5
+    steps, a timed region of 20), a context meets at most six distinct buffers, so that it
+    replays the launch sequences it has recorded (a context keeps eight)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'bench_module', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n_ctx, nbuf0 in ((8, 12), (4, 12), (4, 4), (1, 12), (6, 12)):
+        nbuf = bench.graph_friendly_buffers(nbuf0, n_ctx)
+        assert 1 <= nbuf <= nbuf0
+        seen = {}
+        count = 0
+        for run_length in (3 * max(nbuf0, 2 * n_ctx), 5, 20, 7, 200, 1):
+            for _ in range(run_length):
+                seen.setdefault(count % n_ctx, set()).add(count % nbuf)
+                count += 1
+        assert max(len(v) for v in seen.values()) <= 6, (n_ctx, nbuf, seen)
