@@ -261,7 +261,7 @@ def run_single(env):
     # Distinct input buffers, used in turn, so that no step finds its inputs in the caches left
     # by the step before (together they exceed the 256 MiB Infinity Cache at 368^2): buffer k
     # holds the batch rotated by k images, i.e. image b of buffer k is image (b + k) % B.
-    GATHER_DEPTH = 2   # decodes per context between two gathers
+    GATHER_DEPTH = int(os.environ.get('PD_BENCH_GATHER_DEPTH', '2'))   # decodes per context between two gathers
     n_ctx = args.contexts
     per_step = wl['per_step']
     if rounds:
