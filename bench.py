@@ -674,6 +674,15 @@ def run_multiscale(env):
         for e in engs:
             e.ctx.set_host_results(False)
 
+    stored = os.environ.get('PD_BENCH_MS_STORED') == '1'   # comparison runs: write the averaged maps out, decode those
+
+    def decode(e):
+        if stored:
+            e.ctx.upsample_avg_device(hp, pp, sizes, crops, H, W, B)
+            e.ctx.decode_fullres(0.1, 0.05)
+        else:
+            e.ctx.decode_multiscale(hp, pp, sizes, crops, H, W, B, 0.1, 0.05)
+
     def run(nsteps):
         if gather is not None:
             n, r, done, last = len(engs), 0, 0, None
@@ -687,8 +696,7 @@ def run_multiscale(env):
                 k = min(n, nsteps - done)
                 for j in range(k):
                     gather.point(s, j, j)
-                    engs[j].ctx.upsample_avg_device(hp, pp, sizes, crops, H, W, B)
-                    engs[j].ctx.decode_fullres(0.1, 0.05)
+                    decode(engs[j])
                 gather.start(s)
                 busy[s] = True
                 done += k
@@ -705,8 +713,7 @@ def run_multiscale(env):
             e = engs[i % len(engs)]
             if len(pending) == len(engs):
                 last = pending.pop(0).ctx.fetch()
-            e.ctx.upsample_avg_device(hp, pp, sizes, crops, H, W, B)
-            e.ctx.decode_fullres(0.1, 0.05)
+            decode(e)
             pending.append(e)
         while pending:
             last = pending.pop(0).ctx.fetch()

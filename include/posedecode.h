@@ -111,6 +111,25 @@ int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* heat, const f
                     const int32_t* crop_w, int H, int W, int B, int mem);
 int pd_read_fullres(pd_ctx* ctx, double* heat_out, double* paf_out);
 
+/* The same scale loop (predict.py:51-72) as the source of the decode that follows it
+ * (predict.py:82-254), without the averaged maps ever being stored: the arguments are those of
+ * pd_upsample_avg, the arrays of every scale must stay valid (device-resident ones: unchanged)
+ * until the decode has finished.  pd_set_multiscale only installs the source -- pd_peaks /
+ * pd_connections / pd_parse / pd_decode_fullres then work on it -- and pd_decode_multiscale is
+ * the whole of detect() behind the network calls in one enqueue: the peak stage finds the
+ * candidate cells from bounds on the smoothed average, filters them in float32 and decides
+ * every candidate in exact float64 arithmetic from the four sources (heat channel 18, which
+ * predict.py:91 never reads, is not touched); the PAF average is evaluated at the sample
+ * points of the candidate pairs only (predict.py:136-152).  Results are those of
+ * pd_upsample_avg + pd_decode_fullres, bit for bit.  pd_read_fullres is not available on
+ * this source (there are no maps to read; use pd_upsample_avg for them). */
+int pd_set_multiscale(pd_ctx* ctx, int n_scales, const float* const* heat, const float* const* paf,
+                      const int32_t* hs, const int32_t* ws, const int32_t* crop_h,
+                      const int32_t* crop_w, int H, int W, int B, int mem);
+int pd_decode_multiscale(pd_ctx* ctx, int n_scales, const float* const* heat, const float* const* paf,
+                         const int32_t* hs, const int32_t* ws, const int32_t* crop_h,
+                         const int32_t* crop_w, int H, int W, int B, double thre1, double thre2, int mem);
+
 /* Full-resolution maps supplied by the caller, as the arguments of
  * get_peaks(heatmap, ..) / get_connections(.., pafs, ..) in utils/postprocess.py:
  * (B, H, W, C) arrays of float32 or float64.  Either pointer may be NULL to keep
@@ -281,7 +300,9 @@ int pd_filter_stats(pd_ctx* ctx, int64_t* out);
  * candidate pairs (an image beyond those gets status PD_E_OVERFLOW, as with a context).
  * Every call on a GPU uses that GPU's one array: calls that overlap on a GPU race, also
  * across streams and threads.  The first call on a device (or any pd_create on it)
- * looks up the array's address and must not run under stream capture. */
+ * looks up the array's address and must not run under stream capture; every later call
+ * enqueues kernels only (no memset, no copy, no host allocation), so a captured call records
+ * kernel nodes and nothing else. */
 #define PD_STATIC_MAX_BATCH 16
 #define PD_STATIC_MAX_SIDE 512
 #define PD_STATIC_PEAKS 64

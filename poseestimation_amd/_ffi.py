@@ -18,7 +18,7 @@ F32, F64, U8 = 0, 1, 2
 IMPL_FAST, IMPL_SIMPLE, IMPL_STREAM = 0, 1, 2
 
 EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mode', 'pd_set_impl',
-           'pd_stream', 'pd_share_stream', 'pd_upsample_avg', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
+           'pd_stream', 'pd_share_stream', 'pd_upsample_avg', 'pd_set_multiscale', 'pd_decode_multiscale', 'pd_read_fullres', 'pd_load_fullres', 'pd_set_lowres',
            'pd_peaks', 'pd_set_peaks', 'pd_connections', 'pd_set_connections', 'pd_parse',
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
            'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay', 'pd_set_host_results',
@@ -107,6 +107,8 @@ def lib():
     L.pd_upsample_avg.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   i32, i32, i32, i32]
+    L.pd_set_multiscale.argtypes = L.pd_upsample_avg.argtypes
+    L.pd_decode_multiscale.argtypes = L.pd_upsample_avg.argtypes[:-1] + [dbl, dbl, i32]
     L.pd_read_fullres.argtypes = [vp, vp, vp]
     L.pd_load_fullres.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32]
     L.pd_set_lowres.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32]
@@ -253,6 +255,24 @@ class Context:
         ch = (C.c_int32 * n)(*[c[0] for c in crops])
         cw = (C.c_int32 * n)(*[c[1] for c in crops])
         self.check(self.L.pd_upsample_avg(self._h, n, hp, pp, hs, ws, ch, cw, H, W, B, MEM_DEVICE))
+
+    @staticmethod
+    def _scale_args(heat_ptrs, paf_ptrs, sizes, crops):
+        n = len(heat_ptrs)
+        return (n, (C.c_void_p * n)(*heat_ptrs), (C.c_void_p * n)(*paf_ptrs),
+                (C.c_int32 * n)(*[s[0] for s in sizes]), (C.c_int32 * n)(*[s[1] for s in sizes]),
+                (C.c_int32 * n)(*[c[0] for c in crops]), (C.c_int32 * n)(*[c[1] for c in crops]))
+
+    def set_multiscale(self, heat_ptrs, paf_ptrs, sizes, crops, H, W, B, mem=MEM_DEVICE):
+        """The network outputs of every test scale as the source of the stages that follow
+        (nothing at full resolution is stored): addresses of the (B, hs, ws, 19) / (B, hs, ws, 38)
+        float32 arrays, ``sizes[m] = (hs, ws)``, ``crops[m]`` = the part of the x8 map kept."""
+        self.check(self.L.pd_set_multiscale(self._h, *self._scale_args(heat_ptrs, paf_ptrs, sizes, crops), H, W, B, mem))
+
+    def decode_multiscale(self, heat_ptrs, paf_ptrs, sizes, crops, H, W, B, thre1, thre2, mem=MEM_DEVICE):
+        """predict.py:49-254 behind the network calls in one enqueue (see pd_decode_multiscale)."""
+        self.check(self.L.pd_decode_multiscale(self._h, *self._scale_args(heat_ptrs, paf_ptrs, sizes, crops), H, W, B,
+                                               float(thre1), float(thre2), mem))
 
     def read_fullres(self, B, H, W, want_heat=True, want_paf=True):
         heat = np.empty((B, H, W, 19), np.float64) if want_heat else None

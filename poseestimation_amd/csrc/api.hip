@@ -5,7 +5,7 @@
 
 #include <vector>
 
-#include "common.h"
+#include "multiscale.h"
 
 #pragma clang fp contract(off)
 
@@ -22,6 +22,18 @@ void pd_set_global_error(const char* fmt, ...) {
 
 #define PD_CHECK_CTX(ctx) \
     if ((ctx) == nullptr) return PD_E_INVALID;
+
+__global__ void pd_k_clear_words(int32_t* p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
+int pd_launch_clear(pd_ctx* ctx, void* p, size_t words) {
+    if (words == 0) return PD_OK;
+    const unsigned blocks = (unsigned)((words + 255) / 256 > 64 ? 64 : (words + 255) / 256);
+    hipLaunchKernelGGL(pd_k_clear_words, dim3(blocks), dim3(256), 0, ctx->stream, (int32_t*)p, (int)words);
+    PD_HIP(ctx, hipGetLastError());
+    return PD_OK;
+}
 
 static int dev_alloc(pd_ctx* ctx, void** p, size_t bytes) {
     *p = nullptr;
@@ -168,6 +180,12 @@ static void stop_worker(pd_ctx* ctx) {
 
 extern "C" int pd_destroy(pd_ctx* ctx) {
     PD_CHECK_CTX(ctx);
+    if (ctx->n_sharers > 0) {
+        // other contexts still launch on this one's stream: it goes with the last of them
+        ctx->destroy_pending = 1;
+        return PD_OK;
+    }
+    pd_ctx* const owner = ctx->owner;
     stop_worker(ctx);
     (void)hipSetDevice(ctx->cfg.device_id);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -192,6 +210,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
     if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
     if (ctx->stream && !ctx->stream_shared) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    if (owner && --owner->n_sharers == 0 && owner->destroy_pending) return pd_destroy(owner);
     return PD_OK;
 }
 
@@ -215,6 +234,7 @@ MapSource pd_heat_source(const pd_ctx* ctx) {
     MapSource s;
     memset(&s, 0, sizeof(s));
     s.kind = ctx->src_kind;
+    if (ctx->src_kind == PD_SRC_MULTI && ctx->ms_heat_full) s.kind = PD_SRC_FULLRES;
     s.h = ctx->h;
     s.w = ctx->w;
     s.H = ctx->H;
@@ -231,6 +251,7 @@ MapSource pd_heat_source(const pd_ctx* ctx) {
 
 MapSource pd_paf_source(const pd_ctx* ctx) {
     MapSource s = pd_heat_source(ctx);
+    s.kind = ctx->src_kind;
     s.lo = ctx->lo_paf;
     s.C = PD_CH_PAF;
     s.full = ctx->full_paf;
@@ -240,6 +261,20 @@ MapSource pd_paf_source(const pd_ctx* ctx) {
 
 static void reset_results(pd_ctx* ctx) {
     ctx->have_peaks = ctx->have_conns = ctx->have_persons = ctx->packed = 0;
+    ctx->done_valid = 0;
+}
+
+// On a stream that carries two contexts a context waits for its own work through an event, so
+// that it does not also wait for what the other context has queued behind it.  The event is
+// recorded behind a whole decode; work queued any other way (the staged entry points) makes it
+// stale, and the wait then falls back to the stream.
+static inline bool waits_by_event(const pd_ctx* ctx) { return ctx->stream_shared || ctx->n_sharers > 0; }
+static int record_done(pd_ctx* ctx) {
+    if (!waits_by_event(ctx)) return PD_OK;
+    if (!ctx->done_ev) PD_HIP(ctx, hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming));
+    PD_HIP(ctx, hipEventRecord(ctx->done_ev, ctx->stream));
+    ctx->done_valid = 1;
+    return PD_OK;
 }
 
 #define PD_PACK_DIRECT_LIMIT ((size_t)1 << 20)  // bytes of packed results up to which the pack kernel writes the host mirror
@@ -339,7 +374,8 @@ extern "C" int pd_load_fullres(pd_ctx* ctx, const void* heat, int heat_dtype, in
         }
         float* amax = nullptr;
         if (which == 0) {  // the candidate filter of the peak stage needs a bound on the heatmaps
-            PD_HIP(ctx, hipMemsetAsync(ctx->full_absmax, 0, (size_t)B * sizeof(float), ctx->stream));
+            rc = pd_launch_clear(ctx, ctx->full_absmax, (size_t)B);
+            if (rc != PD_OK) return rc;
             amax = ctx->full_absmax;
         }
         rc = pd_launch_hwc_to_planar(ctx, dsrc, dtype, C, Cdst, B, H, W, dst, amax);
@@ -400,7 +436,8 @@ extern "C" int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* he
         }
         float* amax = nullptr;
         if (which == 0) {
-            PD_HIP(ctx, hipMemsetAsync(ctx->full_absmax, 0, (size_t)B * sizeof(float), ctx->stream));
+            rc = pd_launch_clear(ctx, ctx->full_absmax, (size_t)B);
+            if (rc != PD_OK) return rc;
             amax = ctx->full_absmax;
         }
         rc = pd_launch_upsample_avg(ctx, n_scales, srcs, C, B, hs, ws, crop_h, crop_w, dst, H, W, amax);
@@ -415,6 +452,113 @@ extern "C" int pd_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* he
     ctx->full_absmax_ok = 1;
     ctx->have_full_heat = ctx->have_full_paf = 1;
     reset_results(ctx);
+    return PD_OK;
+}
+
+MultiSource pd_multi_source(const pd_ctx* ctx) {
+    MultiSource ms;
+    memset(&ms, 0, sizeof(ms));
+    ms.n = ctx->ms_n;
+    ms.pow2 = (ctx->ms_n & (ctx->ms_n - 1)) == 0;
+    ms.H = ctx->H;
+    ms.W = ctx->W;
+    ms.n_div = (float)ctx->ms_n;
+    ms.n_rcp = ms.pow2 ? 1.0f / (float)ctx->ms_n : 0.f;
+    for (int m = 0; m < ctx->ms_n; ++m) {
+        MultiSrc& sc = ms.s[m];
+        sc.heat = ctx->ms_heat[m];
+        sc.paf = ctx->ms_paf[m];
+        sc.hs = ctx->ms_hs[m];
+        sc.ws = ctx->ms_ws[m];
+        sc.crop_h = ctx->ms_crop_h[m];
+        sc.crop_w = ctx->ms_crop_w[m];
+        sc.identity = sc.crop_h == ctx->H && sc.crop_w == ctx->W;
+        if (!sc.identity) {
+            sc.ty = ctx->tabs[2 + m].ty;
+            sc.tx = ctx->tabs[2 + m].tx;
+        }
+    }
+    return ms;
+}
+
+// The network outputs of every test scale as the source of the decode: the averaged maps of
+// predict.py:51-72 are evaluated where the stages need them and are not stored.
+extern "C" int pd_set_multiscale(pd_ctx* ctx, int n_scales, const float* const* heat, const float* const* paf,
+                                 const int32_t* hs, const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w,
+                                 int H, int W, int B, int mem) {
+    PD_CHECK_CTX(ctx);
+    PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    int rc = check_batch(ctx, B, H, W, "pd_set_multiscale");
+    if (rc != PD_OK) return rc;
+    if (n_scales < 1 || !heat || !paf || !hs || !ws || !crop_h || !crop_w) PD_FAIL(ctx, PD_E_INVALID, "pd_set_multiscale: bad arguments");
+    if (n_scales > PD_MAX_SCALES) PD_FAIL(ctx, PD_E_INVALID, "pd_set_multiscale: at most %d scales", PD_MAX_SCALES);
+    for (int m = 0; m < n_scales; ++m) {
+        if (!heat[m] || !paf[m]) PD_FAIL(ctx, PD_E_INVALID, "pd_set_multiscale: scale %d: heat and paf are required", m);
+        if (hs[m] < 1 || ws[m] < 1 || crop_h[m] < 1 || crop_w[m] < 1 || crop_h[m] > 8 * hs[m] || crop_w[m] > 8 * ws[m])
+            PD_FAIL(ctx, PD_E_INVALID, "pd_set_multiscale: scale %d: crop %dx%d of x8 map of %dx%d", m, crop_h[m], crop_w[m], hs[m], ws[m]);
+        if (mem == PD_MEM_DEVICE && (((uintptr_t)heat[m] | (uintptr_t)paf[m]) & 15))
+            PD_FAIL(ctx, PD_E_INVALID, "pd_set_multiscale: device arrays must be 16-byte aligned");
+    }
+    ctx->done_valid = 0;
+    if (mem == PD_MEM_HOST) {
+        // (every scale's array starts 16-byte aligned in the staging area)
+        size_t n_lo_all = 0;
+        for (int m = 0; m < n_scales; ++m) n_lo_all += ((size_t)B * hs[m] * ws[m] + 3) & ~(size_t)3;
+        rc = ensure(ctx, (void**)&ctx->stage_heat, &ctx->stage_heat_cap, n_lo_all * PD_CH_HEAT * sizeof(float));
+        if (rc != PD_OK) return rc;
+        rc = ensure(ctx, (void**)&ctx->stage_paf, &ctx->stage_paf_cap, n_lo_all * PD_CH_PAF * sizeof(float));
+        if (rc != PD_OK) return rc;
+        size_t off = 0;
+        for (int m = 0; m < n_scales; ++m) {
+            const size_t px = (size_t)B * hs[m] * ws[m];
+            PD_HIP(ctx, hipMemcpyAsync(ctx->stage_heat + off * PD_CH_HEAT, heat[m], px * PD_CH_HEAT * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            PD_HIP(ctx, hipMemcpyAsync(ctx->stage_paf + off * PD_CH_PAF, paf[m], px * PD_CH_PAF * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            ctx->ms_heat[m] = ctx->stage_heat + off * PD_CH_HEAT;
+            ctx->ms_paf[m] = ctx->stage_paf + off * PD_CH_PAF;
+            off += (px + 3) & ~(size_t)3;
+        }
+    } else {
+        for (int m = 0; m < n_scales; ++m) {
+            ctx->ms_heat[m] = heat[m];
+            ctx->ms_paf[m] = paf[m];
+        }
+    }
+    for (int m = 0; m < n_scales; ++m) {
+        ctx->ms_hs[m] = hs[m];
+        ctx->ms_ws[m] = ws[m];
+        ctx->ms_crop_h[m] = crop_h[m];
+        ctx->ms_crop_w[m] = crop_w[m];
+        if (crop_h[m] != H || crop_w[m] != W) {
+            rc = pd_upload_tables(ctx, crop_h[m], crop_w[m], H, W, -1.0, -1.0, &ctx->tabs[2 + m]);
+            if (rc != PD_OK) return rc;
+        }
+    }
+    ctx->ms_n = n_scales;
+    ctx->ms_heat_full = 0;
+    ctx->src_kind = PD_SRC_MULTI;
+    ctx->B = B;
+    ctx->H = H;
+    ctx->W = W;
+    ctx->h = ctx->w = 0;
+    ctx->heat_f32 = 0;
+    ctx->have_full_heat = ctx->have_full_paf = 0;
+    reset_results(ctx);
+    return PD_OK;
+}
+
+int pd_ms_materialise_heat(pd_ctx* ctx) {
+    if (ctx->src_kind != PD_SRC_MULTI) PD_FAIL(ctx, PD_E_STATE, "no multi-scale source set");
+    if (ctx->ms_heat_full) return PD_OK;
+    int rc = ensure_full(ctx, ctx->B, ctx->H, ctx->W, true, false);
+    if (rc != PD_OK) return rc;
+    rc = pd_launch_clear(ctx, ctx->full_absmax, (size_t)ctx->B);
+    if (rc != PD_OK) return rc;
+    rc = pd_launch_upsample_avg(ctx, ctx->ms_n, ctx->ms_heat, PD_CH_HEAT, ctx->B, ctx->ms_hs, ctx->ms_ws, ctx->ms_crop_h,
+                                ctx->ms_crop_w, ctx->full_heat, ctx->H, ctx->W, ctx->full_absmax);
+    if (rc != PD_OK) return rc;
+    ctx->full_absmax_ok = 1;
+    ctx->have_full_heat = 1;
+    ctx->ms_heat_full = 1;
     return PD_OK;
 }
 
@@ -445,6 +589,7 @@ extern "C" int pd_peaks(pd_ctx* ctx, double thre1) {
     if (ctx->src_kind == PD_SRC_NONE) PD_FAIL(ctx, PD_E_STATE, "pd_peaks: no source set");
     if (ctx->src_kind == PD_SRC_LOWRES && !ctx->lo_heat) PD_FAIL(ctx, PD_E_STATE, "pd_peaks: no heatmaps set");
     if (ctx->src_kind == PD_SRC_FULLRES && !ctx->have_full_heat) PD_FAIL(ctx, PD_E_STATE, "pd_peaks: no heatmaps loaded");
+    ctx->done_valid = 0;
     int rc = pd_launch_smooth_nms(ctx, thre1, nullptr);
     if (rc != PD_OK) return rc;
     rc = pd_launch_sort_peaks(ctx);
@@ -581,6 +726,7 @@ extern "C" int pd_connections(pd_ctx* ctx, double thre2) {
     if (!ctx->have_peaks) PD_FAIL(ctx, PD_E_STATE, "pd_connections: no peaks (run pd_peaks or pd_set_peaks)");
     if (ctx->src_kind == PD_SRC_LOWRES && !ctx->lo_paf) PD_FAIL(ctx, PD_E_STATE, "pd_connections: no PAFs set");
     if (ctx->src_kind == PD_SRC_FULLRES && !ctx->have_full_paf) PD_FAIL(ctx, PD_E_STATE, "pd_connections: no PAFs loaded");
+    ctx->done_valid = 0;
     int rc = pd_launch_pairs(ctx, thre2);
     if (rc != PD_OK) return rc;
     rc = pd_launch_match(ctx);
@@ -640,6 +786,7 @@ extern "C" int pd_parse(pd_ctx* ctx) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     if (!ctx->have_conns) PD_FAIL(ctx, PD_E_STATE, "pd_parse: no connections (run pd_connections or pd_set_connections)");
+    ctx->done_valid = 0;
     int rc = pd_launch_parse(ctx);
     if (rc != PD_OK) return rc;
     ctx->have_persons = 1;
@@ -676,6 +823,7 @@ extern "C" int pd_pack(pd_ctx* ctx) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     if (!ctx->have_peaks && !ctx->have_conns && !ctx->have_persons) PD_FAIL(ctx, PD_E_STATE, "pd_pack: nothing to pack");
+    ctx->done_valid = 0;
     int rc = pd_launch_pack(ctx);
     if (rc != PD_OK) return rc;
     return after_pack(ctx);
@@ -726,9 +874,9 @@ static int prof_harvest(pd_ctx* ctx) {
 
 // Waits for the packed results and completes the host mirror.
 static int finish_results(pd_ctx* ctx) {
-    // (on a shared stream: for this context's last decode only, not for what the other context
-    // has queued behind it)
-    if (ctx->stream_shared && ctx->done_valid)
+    // (on a stream that carries two contexts: for this context's last decode only, not for what
+    // the other context has queued behind it)
+    if (waits_by_event(ctx) && ctx->done_valid)
         PD_HIP(ctx, hipEventSynchronize(ctx->done_ev));
     else
         PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -768,8 +916,28 @@ static void choose_pairs_kernel(pd_ctx* ctx) {
         ctx->pairs_pre = (long long)ctx->H * ctx->W > 512LL * 512LL;
 }
 
+static int decode_fullres_enqueue(pd_ctx* ctx, double thre1, double thre2);
+
 extern "C" int pd_decode_fullres(pd_ctx* ctx, double thre1, double thre2) {
     PD_CHECK_CTX(ctx);
+    int rc = decode_fullres_enqueue(ctx, thre1, thre2);
+    if (rc != PD_OK) return rc;
+    return record_done(ctx);
+}
+
+extern "C" int pd_decode_multiscale(pd_ctx* ctx, int n_scales, const float* const* heat, const float* const* paf,
+                                    const int32_t* hs, const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w,
+                                    int H, int W, int B, double thre1, double thre2, int mem) {
+    PD_CHECK_CTX(ctx);
+    int rc = pd_set_multiscale(ctx, n_scales, heat, paf, hs, ws, crop_h, crop_w, H, W, B, mem);
+    if (rc != PD_OK) return rc;
+    if (ctx->pack_policy < 0) ctx->pack_direct = ctx->last_result_bytes <= PD_PACK_DIRECT_LIMIT;
+    rc = decode_fullres_enqueue(ctx, thre1, thre2);
+    if (rc != PD_OK) return rc;
+    return record_done(ctx);
+}
+
+static int decode_fullres_enqueue(pd_ctx* ctx, double thre1, double thre2) {
     choose_pairs_kernel(ctx);  // (inside pd_decode_batch: the same answer as the one its launch-sequence key holds)
     int rc = pd_peaks(ctx, thre1);
     if (rc != PD_OK) return rc;
@@ -794,11 +962,8 @@ extern "C" int pd_decode_batch(pd_ctx* ctx, const float* heat, const float* paf,
     if (!heat || !paf) PD_FAIL(ctx, PD_E_INVALID, "pd_decode_batch: heat and paf are required");
     ctx->done_valid = 0;
     int rc = decode_batch_enqueue(ctx, heat, paf, B, h, w, H, W, thre1, thre2, mem);
-    if (rc == PD_OK && ctx->stream_shared) {
-        PD_HIP(ctx, hipEventRecord(ctx->done_ev, ctx->stream));
-        ctx->done_valid = 1;
-    }
-    return rc;
+    if (rc != PD_OK) return rc;
+    return record_done(ctx);
 }
 
 extern "C" int pd_share_stream(pd_ctx* ctx, pd_ctx* owner) {
@@ -811,10 +976,12 @@ extern "C" int pd_share_stream(pd_ctx* ctx, pd_ctx* owner) {
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int rc = drop_graphs(ctx);
     if (rc != PD_OK) return rc;
-    if (!ctx->done_ev) PD_HIP(ctx, hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming));
     PD_HIP(ctx, hipStreamDestroy(ctx->stream));
     ctx->stream = owner->stream;
     ctx->stream_shared = 1;
+    ctx->owner = owner;
+    owner->n_sharers++;
+    owner->done_valid = 0;  // (the owner waits through its event from now on as well)
     ctx->done_valid = 0;
     ctx->gen++;
     return PD_OK;
@@ -827,11 +994,11 @@ static int decode_batch_enqueue(pd_ctx* ctx, const float* heat, const float* paf
     if (mem != PD_MEM_DEVICE || !ctx->use_graph) {
         if (ctx->pack_policy < 0) ctx->pack_direct = ctx->last_result_bytes <= PD_PACK_DIRECT_LIMIT;
     choose_pairs_kernel(ctx);
-        return pd_decode_fullres(ctx, thre1, thre2);
+        return decode_fullres_enqueue(ctx, thre1, thre2);
     }
 
-    // Device-resident input: the whole launch sequence (about a dozen kernels, three
-    // memsets, the result copy and, when profiling, the event pairs) is captured into a
+    // Device-resident input: the whole launch sequence (six to nine kernels, the result copy
+    // of large results and, when profiling, the event pairs) is captured into a
     // HIP graph the second time the same call is seen and replayed from then on, which
     // takes the per-launch host cost out of the steady state.
     if (ctx->pack_policy < 0) ctx->pack_direct = ctx->last_result_bytes <= PD_PACK_DIRECT_LIMIT;
@@ -861,8 +1028,11 @@ static int decode_batch_enqueue(pd_ctx* ctx, const float* heat, const float* paf
         if (g.seen && memcmp(&key, &g.key, sizeof(key)) == 0) slot = &g;
     const uint64_t now = ++ctx->graph_clock;
     if (slot && slot->exec) {
-        // the recorded sequence holds no memset: it relies on the counters being zero
-        if (!ctx->zero_clean) PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));
+        // the recorded sequence holds no clear: it relies on the counters being zero
+        if (!ctx->zero_clean) {
+            rc = pd_launch_clear(ctx, ctx->zero_block, ctx->zero_bytes / sizeof(int32_t));
+            if (rc != PD_OK) return rc;
+        }
         PD_HIP(ctx, hipGraphLaunch(slot->exec, ctx->stream));
         slot->used = now;
         ctx->zero_clean = 1;
@@ -891,7 +1061,7 @@ static int decode_batch_enqueue(pd_ctx* ctx, const float* heat, const float* paf
         victim->key = key;
         victim->seen = 1;
         victim->used = now;
-        return pd_decode_fullres(ctx, thre1, thre2);
+        return decode_fullres_enqueue(ctx, thre1, thre2);
     }
     slot->used = now;
     if (ctx->prof_n > 0) {  // pairs of earlier eager calls must not be mixed into the captured set
@@ -900,25 +1070,23 @@ static int decode_batch_enqueue(pd_ctx* ctx, const float* heat, const float* paf
         if (rc != PD_OK) return rc;
     }
     hipGraph_t graph = nullptr;
-    // A recorded sequence must not hold a memset node: replaying one next to a live RCCL
-    // communicator ended in a GPU memory fault (ROCm 7.2; reproduced with the switch below,
-    // never without the node).  Normally the pack kernel of the previous decode has left the
-    // counters zero; if not, they are cleared in front of the recording, not inside it.
+    // Normally the pack kernel of the previous decode has left the counters zero; if not, they
+    // are cleared in front of the recording (by a kernel: the library queues no memset on a
+    // decode path, so no sequence it or a caller records can hold a memset node).
     if (!ctx->zero_clean) {
-        PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));
+        rc = pd_launch_clear(ctx, ctx->zero_block, ctx->zero_bytes / sizeof(int32_t));
+        if (rc != PD_OK) return rc;
         ctx->zero_clean = 1;
     }
-    // diagnostics only (tools/graph_pg_probe.py): record the memset node all the same
-    if (getenv("PD_DEBUG_GRAPH_MEMSET")) ctx->zero_clean = 0;
     PD_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    rc = pd_decode_fullres(ctx, thre1, thre2);
+    rc = decode_fullres_enqueue(ctx, thre1, thre2);
     const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != PD_OK || e_end != hipSuccess || graph == nullptr) {
         if (graph) (void)hipGraphDestroy(graph);
         ctx->use_graph = 0;  // capture is not possible here: stay eager from now on
         ctx->prof_n = 0;
         if (rc != PD_OK) return rc;
-        return pd_decode_fullres(ctx, thre1, thre2);
+        return decode_fullres_enqueue(ctx, thre1, thre2);
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -926,13 +1094,13 @@ static int decode_batch_enqueue(pd_ctx* ctx, const float* heat, const float* paf
     if (e_inst != hipSuccess) {
         ctx->use_graph = 0;
         ctx->prof_n = 0;
-        return pd_decode_fullres(ctx, thre1, thre2);
+        return decode_fullres_enqueue(ctx, thre1, thre2);
     }
     if (ctx->gen != key.gen) {  // something moved while recording: the sequence is already stale
         (void)hipGraphExecDestroy(exec);
         memset(slot, 0, sizeof(*slot));
         ctx->prof_n = 0;
-        return pd_decode_fullres(ctx, thre1, thre2);
+        return decode_fullres_enqueue(ctx, thre1, thre2);
     }
     slot->exec = exec;
     slot->res_have = ctx->res_have;

@@ -182,23 +182,33 @@ extern "C" int pd_gather(pd_comm* c, pd_ctx* const* ctxs, int n_ctx, int root, v
     // every context's decode must have reached its skeleton buffer; its header gives the size
     int64_t mine[PD_GATHER_MAX_CTX];
     memset(mine, 0, sizeof(mine));
-    int short_ctx = -1;
+    int short_ctx = -1, bad_ctx = -1;
     long long short_need = 0;
     for (int i = 0; i < n_ctx; ++i) {
         pd_ctx* x = ctxs[i];
         if (!x || !x->skel_dst) CM_FAIL(c, PD_E_STATE, "pd_gather: context %d has no skeleton buffer (pd_set_skeleton_buffer)", i);
         if (x->cfg.device_id != c->device) CM_FAIL(c, PD_E_INVALID, "pd_gather: context %d is on another device", i);
+        if (x->worker && pd_flush(x) != PD_OK)  // decodes queued with pd_submit have been launched
+            CM_FAIL(c, PD_E_STATE, "pd_gather: context %d: %s", i, x->err);
         CM_HIP(c, hipStreamSynchronize(x->stream));
         int64_t head[8];
         CM_HIP(c, hipMemcpy(head, x->skel_dst, sizeof(head), hipMemcpyDeviceToHost));
-        if (head[5] != 0) {
+        const bool sane = head[0] >= 1 && head[0] <= x->cfg.max_batch && head[1] >= 0 && head[2] >= 0 && head[3] >= 0;
+        if (sane && head[5] != 0) {
             // the buffer was too small for the payload: the header (which says so) and the count
             // tables still travel, so that no rank is left waiting; reported after the exchange
             short_ctx = i;
             short_need = (long long)head[5];
             mine[i] = (int64_t)pd_res_layout((int)head[0]).off_payload;
-        } else {
+        } else if (sane) {
             mine[i] = (int64_t)blob_bytes(head);
+        }
+        if (!sane || (uint64_t)mine[i] > (uint64_t)x->skel_cap) {
+            // no decode has written this buffer (or not this one): a send sized from its header would
+            // read past its end.  The size -1 travels in the count exchange, so that every rank
+            // gives up together instead of waiting for this one.
+            bad_ctx = i;
+            mine[i] = -1;
         }
     }
     // 1. byte counts of every rank
@@ -209,42 +219,60 @@ extern "C" int pd_gather(pd_comm* c, pd_ctx* const* ctxs, int n_ctx, int root, v
     CM_HIP(c, hipMemcpyAsync(c->counts_host, c->counts_dev, (size_t)c->world * PD_GATHER_MAX_CTX * sizeof(int64_t),
                              hipMemcpyDeviceToHost, c->stream));
     CM_HIP(c, hipStreamSynchronize(c->stream));
+    if (bad_ctx >= 0)
+        CM_FAIL(c, PD_E_STATE, "pd_gather: context %d: its skeleton buffer (%llu bytes) does not hold the results of a decode",
+                bad_ctx, (unsigned long long)ctxs[bad_ctx]->skel_cap);
     uint64_t total = 0;
     for (int r = 0; r < c->world; ++r)
         for (int i = 0; i < PD_GATHER_MAX_CTX; ++i) {
             const int64_t v = c->counts_host[(size_t)r * PD_GATHER_MAX_CTX + i];
-            if (v < 0) CM_FAIL(c, PD_E_STATE, "pd_gather: rank %d reported a negative size", r);
+            if (v < 0) CM_FAIL(c, PD_E_STATE, "pd_gather: rank %d has a skeleton buffer that holds no decode results", r);
             if ((v != 0) != (i < n_ctx))
                 CM_FAIL(c, PD_E_INVALID, "pd_gather: rank %d brought another number of contexts than this rank (%d)", r, n_ctx);
             total += (uint64_t)((v + 15) & ~(int64_t)15);   // every buffer starts 16-byte aligned
         }
     if (total_bytes) *total_bytes = total;
     const bool is_root = c->rank == root;
-    if (is_root) {
-        // the root always takes part in the exchange (the other ranks are already committed to
-        // their sends); a host array that is too small is reported after it
-        if (c->recv_cap < total) {
-            if (c->recv_dev) CM_HIP(c, hipFree(c->recv_dev));
-            c->recv_dev = nullptr;
-            c->recv_cap = 0;
-            CM_HIP(c, hipMalloc((void**)&c->recv_dev, total));
+    // the root's receive area; whether it could be had travels to every rank before anyone sends
+    int64_t ready = 1;
+    if (is_root && c->recv_cap < total) {
+        if (c->recv_dev) (void)hipFree(c->recv_dev);
+        c->recv_dev = nullptr;
+        c->recv_cap = 0;
+        if (hipMalloc((void**)&c->recv_dev, total) == hipSuccess)
             c->recv_cap = total;
-        }
+        else
+            ready = 0;
     }
-    // 2. the buffers themselves: one send per context, one receive per (rank, context) on the root
-    CM_RCCL(c, g_rccl.GroupStart());
-    for (int i = 0; i < n_ctx; ++i) CM_RCCL(c, g_rccl.Send(ctxs[i]->skel_dst, (size_t)mine[i], RC_UINT8, root, c->comm, c->stream));
+    if (c->world > 1) {
+        int64_t* flags = c->counts_dev;  // (the counts have been copied out)
+        CM_HIP(c, hipMemcpyAsync(flags + c->rank, &ready, sizeof(ready), hipMemcpyHostToDevice, c->stream));
+        CM_RCCL(c, g_rccl.AllGather(flags + c->rank, flags, 1, RC_INT64, c->comm, c->stream));
+        int64_t root_ready = 0;
+        CM_HIP(c, hipMemcpyAsync(&root_ready, flags + root, sizeof(root_ready), hipMemcpyDeviceToHost, c->stream));
+        CM_HIP(c, hipStreamSynchronize(c->stream));
+        ready = root_ready;
+    }
+    if (!ready) CM_FAIL(c, PD_E_HIP, "pd_gather: rank %d could not allocate %llu bytes for the gathered buffers", root, (unsigned long long)total);
+    // 2. the buffers themselves: one send per context, one receive per (rank, context) on the root.
+    // A group that was opened is always closed; the first failure inside it is reported afterwards.
+    rc_result first = g_rccl.GroupStart();
+    if (first != 0) CM_FAIL(c, PD_E_HIP, "ncclGroupStart failed: %s", g_rccl.GetErrorString(first));
+    for (int i = 0; i < n_ctx && first == 0; ++i)
+        first = g_rccl.Send(ctxs[i]->skel_dst, (size_t)mine[i], RC_UINT8, root, c->comm, c->stream);
     if (is_root) {
         size_t off = 0;
         for (int r = 0; r < c->world; ++r)
             for (int i = 0; i < n_ctx; ++i) {
                 const size_t v = (size_t)c->counts_host[(size_t)r * PD_GATHER_MAX_CTX + i];
-                CM_RCCL(c, g_rccl.Recv(c->recv_dev + off, v, RC_UINT8, r, c->comm, c->stream));
+                if (first == 0) first = g_rccl.Recv(c->recv_dev + off, v, RC_UINT8, r, c->comm, c->stream);
                 if (sizes) sizes[(size_t)r * n_ctx + i] = v;
                 off += (v + 15) & ~(size_t)15;
             }
     }
-    CM_RCCL(c, g_rccl.GroupEnd());
+    const rc_result ended = g_rccl.GroupEnd();
+    if (first == 0) first = ended;
+    if (first != 0) CM_FAIL(c, PD_E_HIP, "pd_gather: the exchange failed: %s", g_rccl.GetErrorString(first));
     const bool fits = !is_root || (recv_host != nullptr && recv_capacity >= total);
     if (is_root && fits) CM_HIP(c, hipMemcpyAsync(recv_host, c->recv_dev, total, hipMemcpyDeviceToHost, c->stream));
     CM_HIP(c, hipStreamSynchronize(c->stream));

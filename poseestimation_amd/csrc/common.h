@@ -21,7 +21,7 @@
 #define PD_MID 10     // sample points per limb candidate (utils/postprocess.py:79)
 #define PD_MAX_SCALES 8  // scales of one pd_upsample_avg call
 
-enum { PD_SRC_NONE = 0, PD_SRC_LOWRES = 1, PD_SRC_FULLRES = 2 };
+enum { PD_SRC_NONE = 0, PD_SRC_LOWRES = 1, PD_SRC_FULLRES = 2 };  // and PD_SRC_MULTI = 3 (multiscale.h)
 
 struct RawPeak {
     int32_t y, x;
@@ -151,6 +151,12 @@ struct pd_ctx {
     double* full_paf;   // (B, 38, H, W)
     size_t full_heat_cap, full_paf_cap;
     int have_full_heat, have_full_paf;
+    // ---- multi-scale source (pd_set_multiscale): the network outputs of every test scale ----
+    int ms_n;
+    const float* ms_heat[PD_MAX_SCALES];  // (B, hs, ws, 19)
+    const float* ms_paf[PD_MAX_SCALES];   // (B, hs, ws, 38)
+    int32_t ms_hs[PD_MAX_SCALES], ms_ws[PD_MAX_SCALES], ms_crop_h[PD_MAX_SCALES], ms_crop_w[PD_MAX_SCALES];
+    int ms_heat_full;  // the heat average of the current source has been written to full_heat
     void* tmp_in;  // staging for host-resident full-resolution input
     size_t tmp_in_cap;
     double* tmp_smooth;  // (B, 18, H, W) scratch of the simple path / debug hook
@@ -189,8 +195,11 @@ struct pd_ctx {
     // Two contexts may launch on one stream (pd_share_stream): the second decode queues behind the
     // first, and a context then waits for its own last decode through an event, not for the stream.
     int stream_shared;    // the stream belongs to another context: not destroyed with this one
-    hipEvent_t done_ev;   // recorded behind every pd_decode_batch of a context that shares a stream
-    int done_valid;
+    pd_ctx* owner;        // that context
+    int n_sharers;        // contexts that launch on this one's stream
+    int destroy_pending;  // pd_destroy was called while sharers were left: freed with the last of them
+    hipEvent_t done_ev;   // recorded behind every whole decode of a context whose stream carries two contexts
+    int done_valid;       // done_ev marks the end of everything this context has queued
     int32_t* pack_ticket; // behind the block: arrival counter of k_parse_pack, zero between launches (NULL: not available)
     int64_t* fstats;     // what pd_filter_stats reports, summed up by k_sort_peaks before the counters go
     RawPeak* raw;        // [B][18][PK] unordered
@@ -267,6 +276,12 @@ struct pd_ctx {
 void pd_set_global_error(const char* fmt, ...);
 // Per-device set-up of the allocation-free entry point (address of its scratch array).
 int pd_static_setup(int device, char* err, size_t err_len);
+
+// Zeroes `words` 32-bit words at `p` with a kernel on the context's stream.  Decode paths never
+// queue a memset: a sequence a caller captures into a HIP graph then holds kernel nodes only
+// (a memset node replayed next to a live RCCL communicator ended in a GPU memory fault on ROCm 7.2).
+int pd_launch_clear(pd_ctx* ctx, void* p, size_t words);
+__global__ void pd_k_clear_words(int32_t* p, int n);
 
 // Record a start / stop event pair around a stage's kernel launch when profiling is on.
 void pd_prof_begin(pd_ctx* ctx, int stage);
@@ -397,3 +412,8 @@ __device__ __forceinline__ void pd_wave_absmax(float m, float* dst) {
 }
 MapSource pd_heat_source(const pd_ctx* ctx);
 MapSource pd_paf_source(const pd_ctx* ctx);
+// Multi-scale source: writes the float64 average of the heatmaps to full_heat (the peak stage
+// then reads it as a full-resolution source).
+int pd_ms_materialise_heat(pd_ctx* ctx);
+// PD_E_STATE when the geometry has no tables for the sparse multi-scale peak stage (caller falls back)
+int pd_launch_peaks_filtered_multi(pd_ctx* ctx, double thr);

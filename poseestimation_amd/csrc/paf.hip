@@ -12,8 +12,8 @@
 #include <math.h>
 #include <stdlib.h>
 
-#include "common.h"
 #include "match.h"
+#include "multiscale.h"
 
 #pragma clang fp contract(off)
 
@@ -154,7 +154,10 @@ __device__ __forceinline__ bool pair_geometry(const PairArgs& a, int b, int p, c
 }
 
 // v0 * u0 + v1 * u1 at sample i of the pair (i = 9 is the second peak itself).
-__device__ __forceinline__ double pair_sample(const PairArgs& a, int b, const PairGeo& g, int i, const float4* s_up) {
+// MULTI: the PAF values are the average over the test scales of *ms, evaluated at the sample.
+template <bool MULTI>
+__device__ __forceinline__ double pair_sample(const PairArgs& a, const MultiSource* ms, int b, const PairGeo& g, int i,
+                                              const float4* s_up) {
     const int H = a.src.H, W = a.src.W;
     double py, px;
     if (i == PD_MID - 1) {
@@ -175,7 +178,12 @@ __device__ __forceinline__ double pair_sample(const PairArgs& a, int b, const Pa
     iy = pd_clampi(iy, 0, H - 1);
     ix = pd_clampi(ix, 0, W - 1);
     double v0, v1;
-    if (a.src.kind == PD_SRC_LOWRES) {
+    if (MULTI) {
+        double o[2];
+        pd_ms_avg_at<2>(*ms, true, b, 2 * g.k, iy, ix, s_up, o);
+        v0 = o[0];
+        v1 = o[1];
+    } else if (a.src.kind == PD_SRC_LOWRES) {
         float f0, f1;
         if (a.pairs)
             bicubic2_planar(a.pairs + ((size_t)b * PD_N_LIMBS + g.k) * a.src.h * a.src.w * 2, a.src.h, a.src.w, iy, ix,
@@ -197,15 +205,16 @@ __device__ __forceinline__ double pair_sample(const PairArgs& a, int b, const Pa
 // Scores up to six pairs whose geometry (k < 0: nothing to do) and pair indices lie in
 // geo[0..5] / p6[0..5]: ten lanes per pair take one sample point each, and lane 0 of each
 // group adds the ten products in sample order.
-__device__ __forceinline__ void score_six(const PairArgs& a, int b, int lane, const float4* s_up, const PairGeo* geo,
-                                          const int* p6, int n, double (*mid6)[10]) {
+template <bool MULTI>
+__device__ __forceinline__ void score_six(const PairArgs& a, const MultiSource* ms, int b, int lane, const float4* s_up,
+                                          const PairGeo* geo, const int* p6, int n, double (*mid6)[10]) {
     const int cs = lane / 10, i = lane - cs * 10;
     double mid = 0.0;
     int k = -1;
     if (cs < n) k = geo[cs].k;
     if (k >= 0) {
         const PairGeo g = geo[cs];
-        mid = pair_sample(a, b, g, i, s_up);
+        mid = pair_sample<MULTI>(a, ms, b, g, i, s_up);
     }
     if (cs < 6) mid6[cs][i] = mid;
     pd_wave_sync();  // lane 0 of a group reads what the other nine wrote
@@ -239,9 +248,8 @@ __device__ __forceinline__ void score_six(const PairArgs& a, int b, int lane, co
 // PRE = false: the kernel without the pre-test (every image takes the direct form, whatever its
 // number of pairs: same results), a fifth of the LDS and fewer registers; the host picks it for
 // decodes whose images hold few peaks.
-template <bool PRE>
-__global__ void __launch_bounds__(256)
-k_pair_scores(PairArgs a) {
+template <bool PRE, bool MULTI>
+__device__ __forceinline__ void pair_scores_body(const PairArgs& a, const MultiSource* ms) {
     __shared__ int32_t s_off[PD_N_LIMBS + 1];
     __shared__ int32_t s_cnt[PD_N_PARTS];
     __shared__ float4 s_up[8];
@@ -280,7 +288,7 @@ k_pair_scores(PairArgs a) {
                 pq[lane] = p;
             }
             pd_wave_sync();  // the staging area is private to this wavefront; all lanes read what six wrote
-            score_six(a, b, lane, s_up, geo, pq, min(PAIRS_PER_CHUNK, total - base), s_mid[wv]);
+            score_six<MULTI>(a, ms, b, lane, s_up, geo, pq, min(PAIRS_PER_CHUNK, total - base), s_mid[wv]);
         }
         return;
     }
@@ -322,7 +330,7 @@ k_pair_scores(PairArgs a) {
                 if (idx < nq) {
                     g = geo[idx];
                     p = pq[idx];
-                    const double ma = pair_sample(a, b, g, ia, s_up), mb = pair_sample(a, b, g, ib, s_up);
+                    const double ma = pair_sample<MULTI>(a, ms, b, g, ia, s_up), mb = pair_sample<MULTI>(a, ms, b, g, ib, s_up);
                     g.pad += (ma > a.thr ? 0 : 1) + (mb > a.thr ? 0 : 1);  // samples at or under the threshold so far
                     survives = g.pad < 2;
                     if (!survives) a.pair_score[(size_t)b * a.max_pairs + p] = -1.0;
@@ -340,8 +348,23 @@ k_pair_scores(PairArgs a) {
             nq = kept;
         }
         for (int q0 = 0; q0 < nq; q0 += PAIRS_PER_CHUNK)
-            score_six(a, b, lane, s_up, geo + q0, pq + q0, min(PAIRS_PER_CHUNK, nq - q0), s_mid[wv]);
+            score_six<MULTI>(a, ms, b, lane, s_up, geo + q0, pq + q0, min(PAIRS_PER_CHUNK, nq - q0), s_mid[wv]);
     }
+}
+
+template <bool PRE>
+__global__ void __launch_bounds__(256)
+k_pair_scores(PairArgs a) {
+    pair_scores_body<PRE, false>(a, nullptr);
+}
+
+// The same on a multi-scale source: every PAF value is the average over the test scales of the
+// two-step bicubic resize, evaluated at the sample from the network outputs themselves (a few
+// thousand samples per image instead of 38 full-resolution planes).
+template <bool PRE>
+__global__ void __launch_bounds__(256)
+k_pair_scores_ms(PairArgs a, MultiSource ms) {
+    pair_scores_body<PRE, true>(a, &ms);
 }
 
 // ---------------------------------------------------------------------------------
@@ -412,6 +435,17 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
             ctx->paf_pairs_cap = paf_bytes;
         }
         a.pairs = ctx->paf_pairs;
+    }
+    if (a.src.kind == PD_SRC_MULTI) {
+        const MultiSource ms = pd_multi_source(ctx);
+        pd_prof_begin(ctx, PD_STAGE_PAIRS);
+        if (ctx->pairs_pre)
+            hipLaunchKernelGGL(k_pair_scores_ms<true>, dim3(per_image * ctx->B), dim3(256), 0, ctx->stream, a, ms);
+        else
+            hipLaunchKernelGGL(k_pair_scores_ms<false>, dim3(per_image * ctx->B), dim3(256), 0, ctx->stream, a, ms);
+        pd_prof_end(ctx);
+        PD_HIP(ctx, hipGetLastError());
+        return PD_OK;
     }
     pd_prof_begin(ctx, PD_STAGE_PAIRS);
     if (a.pairs)

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "colloader.h"
+#include "multiscale.h"
 #include "peaksort.h"
 
 #pragma clang fp contract(off)
@@ -339,16 +340,30 @@ int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smo
 
 int pd_launch_smooth_nms(pd_ctx* ctx, double thre1, double* dbg_smoothed) {
     const int B = ctx->B, H = ctx->H, W = ctx->W;
-    MapSource src = pd_heat_source(ctx);
     // raw_count and the filter's counters start at zero; the pack kernel of the previous
     // decode has normally seen to that
-    if (!ctx->zero_clean) PD_HIP(ctx, hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream));
+    if (!ctx->zero_clean) {
+        int rc = pd_launch_clear(ctx, ctx->zero_block, ctx->zero_bytes / sizeof(int32_t));
+        if (rc != PD_OK) return rc;
+    }
     ctx->zero_clean = 0;
     const int f32mode = (ctx->src_kind == PD_SRC_FULLRES) ? ctx->heat_f32 : 0;
     // float32 data is thresholded in float32 (numpy compares a float32 array with a
     // Python float in float32)
     const double thr = f32mode ? (double)(float)thre1 : thre1;
     const bool small = H < 2 * PD_GR + 2 || W < 2 * PD_GR + 2;
+    if (ctx->src_kind == PD_SRC_MULTI && !ctx->ms_heat_full) {
+        // the scales of a multi-scale source: candidate cells, float32 filter and exact verification
+        // straight from the network outputs; where that form does not apply the average of the
+        // heatmaps is written out once and the stage runs on it as on any full-resolution map
+        if (ctx->impl == PD_IMPL_FAST && !small && dbg_smoothed == nullptr) {
+            int rc = pd_launch_peaks_filtered_multi(ctx, thr);
+            if (rc != PD_E_STATE) return rc;
+        }
+        int rc = pd_ms_materialise_heat(ctx);
+        if (rc != PD_OK) return rc;
+    }
+    MapSource src = pd_heat_source(ctx);
     if (ctx->impl == PD_IMPL_FAST && !small && src.kind == PD_SRC_LOWRES && dbg_smoothed == nullptr) {
         // float32 candidate filter + exact verification; falls through to the
         // streaming kernel when the geometry has no filter tables

@@ -6,10 +6,11 @@
 // are the ones the context path launches (peak stage: the exact float64 streaming kernel).
 //
 // The array exists once per GPU and keeps the last call's contents: the counters that must
-// start at zero are cleared at the head of every call, everything else is written before
-// it is read.  Calls that overlap on one GPU race on it.
+// start at zero are cleared by the first kernel of every call (the one that fills the tap
+// tables; no memset is queued, so a caller that captures the call records kernel nodes only),
+// everything else is written before it is read.  Calls that overlap on one GPU race on it.
+#include <atomic>
 #include <mutex>
-#include <new>
 
 #include "common.h"
 
@@ -22,8 +23,8 @@ static __device__ __align__(256) unsigned char scratch[ST_BYTES];
 
 // The device address of `scratch` on each GPU (every GPU holds its own copy of the array at
 // its own address).  In host code the array's name is only a handle for hipGetSymbolAddress.
-static unsigned char* g_scratch_ptr[64];
-static pd_ctx* g_view[64];  // host-side description of the carve-up, one per device
+static std::atomic<unsigned char*> g_scratch_ptr[64];
+static pd_ctx g_view[64];  // host-side description of the carve-up, one per device (static storage: zero-initialised)
 static std::mutex g_mu[64];
 static std::mutex g_setup_mu;
 
@@ -33,7 +34,7 @@ int pd_static_setup(int device, char* err, size_t err_len) {
         return PD_E_INVALID;
     }
     std::lock_guard<std::mutex> lock(g_setup_mu);
-    if (g_scratch_ptr[device]) return PD_OK;
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return PD_OK;
     int cur = -1;
     hipError_t e = hipGetDevice(&cur);
     if (e == hipSuccess && cur != device) e = hipSetDevice(device);
@@ -44,21 +45,17 @@ int pd_static_setup(int device, char* err, size_t err_len) {
         snprintf(err, err_len, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
         return PD_E_HIP;
     }
-    pd_ctx* v = new (std::nothrow) pd_ctx;
-    if (!v) {
-        snprintf(err, err_len, "static scratch: out of host memory");
-        return PD_E_HIP;
-    }
-    memset(v, 0, sizeof(*v));
-    g_view[device] = v;
-    g_scratch_ptr[device] = p;
+    g_scratch_ptr[device].store(p, std::memory_order_release);
     return PD_OK;
 }
 
 // Fills the x8 tap tables (first tap and Keys weights per destination index) from the
-// closed form: identical to the host-built tables of the context path.
-__global__ void k_fill_up8_tables(int32_t* ofs_y, float* coef_y, int H, int32_t* ofs_x, float* coef_x, int W, Up8 up) {
+// closed form: identical to the host-built tables of the context path.  Also clears the
+// counters that every decode starts from (zero[0 .. zero_words)).
+__global__ void k_fill_up8_tables(int32_t* ofs_y, float* coef_y, int H, int32_t* ofs_x, float* coef_x, int W, Up8 up,
+                                  int32_t* zero, int zero_words) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int j = i; j < zero_words; j += gridDim.x * blockDim.x) zero[j] = 0;
     if (i < H) {
         ofs_y[i] = pd_up8_ofs(i);
         const int p = pd_up8_phase(i);
@@ -123,7 +120,7 @@ extern "C" int pd_decode_batch_static(const float* heat, const float* paf, int B
         pd_set_global_error("pd_decode_batch_static: no current HIP device");
         return PD_E_HIP;
     }
-    if (!g_scratch_ptr[device]) {  // first call on this device (no context was created on it before)
+    if (!g_scratch_ptr[device].load(std::memory_order_acquire)) {  // first call on this device (no context was created on it before)
         char err[256];
         const int rc = pd_static_setup(device, err, sizeof(err));
         if (rc != PD_OK) {
@@ -132,9 +129,9 @@ extern "C" int pd_decode_batch_static(const float* heat, const float* paf, int B
         }
     }
     std::lock_guard<std::mutex> lock(g_mu[device]);  // host-side state only: overlapping calls still race on the GPU
-    pd_ctx* v = g_view[device];
+    pd_ctx* v = &g_view[device];
     const size_t PK = PD_STATIC_PEAKS, NB = PD_STATIC_MAX_BATCH;
-    Carver c = {g_scratch_ptr[device], 0};
+    Carver c = {g_scratch_ptr[device].load(std::memory_order_acquire), 0};
     v->cfg.device_id = device;
     v->cfg.max_batch = PD_STATIC_MAX_BATCH;
     v->cfg.max_h = v->cfg.max_w = PD_STATIC_MAX_SIDE;
@@ -189,7 +186,7 @@ extern "C" int pd_decode_batch_static(const float* heat, const float* paf, int B
     v->heat_f32 = 0;
     v->res_dev = (unsigned char*)out;
     v->res_user_cap = (size_t)out_capacity;
-    v->zero_clean = 0;  // the array keeps the last call's counters: the peak stage queues the memset
+    v->zero_clean = 1;  // the array keeps the last call's counters: the table kernel below clears them
     v->have_peaks = v->have_conns = v->have_persons = 0;
     v->err[0] = 0;
 
@@ -197,7 +194,8 @@ extern "C" int pd_decode_batch_static(const float* heat, const float* paf, int B
     pd_up8_fill(&up);
     const int n = H > W ? H : W;
     hipLaunchKernelGGL(k_fill_up8_tables, dim3((n + 255) / 256), dim3(256), 0, v->stream, tab_i, tab_f, H,
-                       tab_i + PD_STATIC_MAX_SIDE, tab_f + 4 * PD_STATIC_MAX_SIDE, W, up);
+                       tab_i + PD_STATIC_MAX_SIDE, tab_f + 4 * PD_STATIC_MAX_SIDE, W, up, v->zero_block,
+                       (int)(v->zero_bytes / sizeof(int32_t)));
     int rc = pd_launch_smooth_nms(v, thre1, nullptr);
     if (rc == PD_OK) rc = pd_launch_sort_peaks(v);
     v->have_peaks = 1;

@@ -122,11 +122,28 @@ class DecodeEngine:
         self.ctx.upsample_avg(hs_list, ps_list, crops, H, W, B)
         return B, H, W
 
-    def decode_multiscale(self, heat_scales, paf_scales, pads, out_hw, thre1=THRE1, thre2=THRE2):
-        """Multi-scale average then decode, all on the device."""
-        self.upsample_average(heat_scales, paf_scales, pads, out_hw)
-        self.ctx.decode_fullres(thre1, thre2)
+    def decode_multiscale(self, heat_scales, paf_scales, pads, out_hw, thre1=THRE1, thre2=THRE2, materialise=False):
+        """predict.py:51-254 for a batch: the scale loop's average and the decode, on the device.
+        The averaged maps are not stored (``materialise=True``: the older form, which writes
+        them out with ``upsample_average`` and decodes those; same results)."""
+        if materialise:
+            self.upsample_average(heat_scales, paf_scales, pads, out_hw)
+            self.ctx.decode_fullres(thre1, thre2)
+            return self.fetch()
+        hs_list = [np.ascontiguousarray(a, np.float32) for a in heat_scales]
+        ps_list = [np.ascontiguousarray(a, np.float32) for a in paf_scales]
+        B = hs_list[0].shape[0]
+        sizes = [a.shape[1:3] for a in hs_list]
+        crops = [(a.shape[1] * STRIDE - p[0], a.shape[2] * STRIDE - p[1]) for a, p in zip(hs_list, pads)]
+        H, W = out_hw
+        self.ctx.decode_multiscale([a.ctypes.data for a in hs_list], [a.ctypes.data for a in ps_list], sizes, crops,
+                                   H, W, B, thre1, thre2, _ffi.MEM_HOST)
         return self.fetch()
+
+    def enqueue_multiscale_device(self, heat_ptrs, paf_ptrs, sizes, crops, out_hw, B, thre1=THRE1, thre2=THRE2):
+        """The same for device-resident network outputs given by address, without waiting."""
+        H, W = out_hw
+        self.ctx.decode_multiscale(heat_ptrs, paf_ptrs, sizes, crops, H, W, B, thre1, thre2, _ffi.MEM_DEVICE)
 
 
 def upsample_average(net_outputs_per_scale, pads, out_hw):

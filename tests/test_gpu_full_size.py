@@ -190,6 +190,10 @@ def test_config4_batch_128_four_scales():
     again = eng.decode_multiscale(heats, pafs, pads, (H, W))
     for key in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
         assert np.array_equal(res.packed[key], again.packed[key]), key       # deterministic
+    # the form that writes the averaged maps out and decodes those: the same bytes
+    stored = eng.decode_multiscale(heats, pafs, pads, (H, W), materialise=True)
+    for key in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
+        assert np.array_equal(res.packed[key], stored.packed[key]), key
     for b in (0, 77, 127):
         want_h, want_p = ref.upsample_average([h[b] for h in heats], [p[b] for p in pafs], pads, (H, W))
         cand, peaks, subset = ref.decode(want_h, want_p, 0.1, 0.05, 'D')

@@ -201,3 +201,52 @@ def test_two_contexts_on_one_stream_keep_their_results_apart():
     b.close()
     a.close()
     plain.close()
+
+
+def test_sharing_context_waits_for_work_queued_outside_decode_batch():
+    """On a shared stream a context waits for its own last whole decode through an event.  Work
+    queued through the staged entry points or the multi-scale path afterwards must not be
+    fetched on the strength of that old event: every fetch returns the results of the work that
+    was queued last.  The owner may also be closed first: its stream lives as long as the sharer."""
+    import torch
+    from poseestimation_amd import _ffi, synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 368
+    B = 16
+    big = synth.batch(B, H, W, (4, 8), seed0=4100, paf_order='xy')
+    small = synth.batch(B, H, W, (1, 2), seed0=4200, paf_order='xy')
+    plain = DecodeEngine(B, H, W, mode='D', fullres=True)
+    want_big = plain.decode_batch(*big).packed
+    want_small = plain.decode_batch(*small).packed
+    want_ms = plain.decode_multiscale([small[0]], [small[1]], [(0, 0)], (H, W)).packed
+    a = DecodeEngine(B, H, W, mode='D', fullres=True)
+    b = DecodeEngine(B, H, W, mode='D', fullres=True, share_stream_with=a)
+    d_big = [torch.from_numpy(x).cuda() for x in big]
+    keys = ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons')
+    for who in (b, a):      # the sharer and the owner wait the same way
+        for it in range(3):
+            who.enqueue_device(d_big[0].data_ptr(), d_big[1].data_ptr(), B, 46, 46, (H, W))
+            got = who.fetch().packed
+            for key in keys:
+                assert np.array_equal(got[key], want_big[key]), (it, key)
+            # staged entry points on the same context, other input
+            who.ctx.set_lowres(small[0].ctypes.data, small[1].ctypes.data, B, 46, 46, H, W, _ffi.MEM_HOST)
+            who.ctx.peaks(0.1)
+            who.ctx.connections(0.05)
+            who.ctx.parse()
+            who.ctx.pack()
+            got = who.ctx.fetch()
+            for key in keys:
+                assert np.array_equal(got[key], want_small[key]), (it, key)
+            who.enqueue_device(d_big[0].data_ptr(), d_big[1].data_ptr(), B, 46, 46, (H, W))
+            who.fetch()
+            got = who.decode_multiscale([small[0]], [small[1]], [(0, 0)], (H, W)).packed
+            for key in keys:
+                assert np.array_equal(got[key], want_ms[key]), (it, key)
+    a.close()               # the owner first: its stream must outlive b
+    b.enqueue_device(d_big[0].data_ptr(), d_big[1].data_ptr(), B, 46, 46, (H, W))
+    got = b.fetch().packed
+    for key in keys:
+        assert np.array_equal(got[key], want_big[key]), key
+    b.close()
+    plain.close()

@@ -76,3 +76,73 @@ def test_static_entry_rejects_what_its_scratch_cannot_hold():
     assert b'656' in L.pd_last_error(None)
     assert L.pd_decode_batch_static(p, p, 16, 46, 46, 368, 368, 0.1, 0.05, 1, p, 64, None) == _ffi.PD_E_INVALID
     assert b'count tables' in L.pd_last_error(None)
+
+
+def test_static_entry_against_the_oracle():
+    """The allocation-free entry point checked against the CPU restatement itself (not only
+    against the context path)."""
+    import torch
+    from poseestimation_amd import _ffi, synth
+    from poseestimation_amd.predict_decode import Results
+    from oracle import decode_ref as ref
+    L = _ffi.lib()
+    out = torch.zeros(1 << 20, dtype=torch.uint8, device='cuda')
+    heat, paf = synth.batch(4, 184, 248, (1, 4), seed0=77, paf_order='xy')
+    d_heat, d_paf = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    raw = _static_decode(L, torch, d_heat, d_paf, 184, 248, _ffi.MODE_D, out)
+    res = Results(_ffi.unpack_results(raw), _ffi.MODE_D)
+    for b in range(4):
+        hf = ref.resize_cubic(heat[b], fx=8, fy=8).astype(np.float64)
+        pf = ref.resize_cubic(paf[b], fx=8, fy=8).astype(np.float64)
+        cand, peaks, subset = ref.decode(hf, pf, 0.1, 0.05, 'D')
+        g_cand, _, g_subset = res.image(b)
+        assert np.array_equal(g_cand[:, :2], cand[:, :2])
+        assert np.allclose(g_cand[:, 2], cand[:, 2], rtol=1e-5, atol=0)
+        assert g_subset.shape == subset.shape and np.array_equal(g_subset[:, :18], subset[:, :18])
+        assert np.allclose(g_subset[:, 18:], subset[:, 18:], rtol=1e-5, atol=0)
+
+
+def test_static_entry_captured_into_a_graph_holds_kernel_nodes_only_and_replays():
+    """A caller under stream capture: the captured call must record kernel nodes only (no
+    memset node, no copy, no allocation), and three replays of the graph give the results of
+    the context path every time."""
+    import torch
+    from poseestimation_amd import _ffi, synth
+    L = _ffi.lib()
+    hip = C.CDLL('libamdhip64.so')
+    heat, paf = synth.batch(8, 368, 368, (1, 6), seed0=910, paf_order='xy')
+    d_heat, d_paf = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    want = _context_decode(_ffi, d_heat, d_paf, 368, 368, _ffi.MODE_D)
+    out = torch.zeros(1 << 20, dtype=torch.uint8, device='cuda')
+    # (one eager call first: it looks up the scratch array's address, which a capture cannot)
+    _static_decode(L, torch, d_heat, d_paf, 368, 368, _ffi.MODE_D, out)
+    s = torch.cuda.Stream()
+    stream = C.c_void_p(s.cuda_stream)
+    torch.cuda.synchronize()
+    graph, gexec = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamBeginCapture(stream, 1) == 0          # hipStreamCaptureModeThreadLocal
+    rc = L.pd_decode_batch_static(d_heat.data_ptr(), d_paf.data_ptr(), 8, 46, 46, 368, 368, 0.1, 0.05, _ffi.MODE_D,
+                                  out.data_ptr(), out.numel(), stream)
+    assert hip.hipStreamEndCapture(stream, C.byref(graph)) == 0
+    assert rc == 0, L.pd_last_error(None).decode()
+    n = C.c_size_t(0)
+    assert hip.hipGraphGetNodes(graph, None, C.byref(n)) == 0
+    nodes = (C.c_void_p * n.value)()
+    assert hip.hipGraphGetNodes(graph, nodes, C.byref(n)) == 0
+    kinds = []
+    for node in nodes:
+        t = C.c_int(-1)
+        assert hip.hipGraphNodeGetType(C.c_void_p(node), C.byref(t)) == 0
+        kinds.append(t.value)
+    assert n.value >= 6 and all(k == 0 for k in kinds), kinds   # 0 = hipGraphNodeTypeKernel (2 would be a memset)
+    assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)) == 0
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        out.zero_()
+        torch.cuda.synchronize()
+        assert hip.hipGraphLaunch(gexec, stream) == 0
+        assert hip.hipStreamSynchronize(stream) == 0
+        _assert_same(_ffi, out.cpu().numpy(), want)
+    assert torch.cuda.mem_get_info()[0] == free_before
+    hip.hipGraphExecDestroy(gexec)
+    hip.hipGraphDestroy(graph)
