@@ -194,7 +194,8 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pk_x, ctx->pk_id, ctx->pk_score, ctx->part_count, ctx->part_base, ctx->pair_off,
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
-                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats, ctx->full_absmax, ctx->aux_dev, ctx->dbg_found, ctx->plane_slack};
+                    ctx->heat_planar, ctx->paf_pairs, ctx->fstats, ctx->full_absmax, ctx->aux_dev, ctx->dbg_found, ctx->plane_slack,
+                    ctx->msf_tab, ctx->msf_lo, ctx->ms_planar, ctx->ms_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (TableSlot& t : ctx->tabs) {
@@ -543,6 +544,20 @@ extern "C" int pd_set_multiscale(pd_ctx* ctx, int n_scales, const float* const* 
     ctx->heat_f32 = 0;
     ctx->have_full_heat = ctx->have_full_paf = 0;
     reset_results(ctx);
+    {
+        // the scales also live in device memory, for the kernel that reads them through a pointer;
+        // rewritten (stream-ordered) only when they change
+        static_assert(sizeof(MultiSource) <= sizeof(ctx->ms_dev_image), "ms_dev_image holds a MultiSource");
+        const MultiSource ms = pd_multi_source(ctx);
+        if (!ctx->ms_dev) {
+            PD_HIP(ctx, hipMalloc(&ctx->ms_dev, sizeof(ctx->ms_dev_image)));
+            memset(ctx->ms_dev_image, 0xff, sizeof(ctx->ms_dev_image));
+        }
+        if (memcmp(&ms, ctx->ms_dev_image, sizeof(ms)) != 0) {
+            memcpy(ctx->ms_dev_image, &ms, sizeof(ms));
+            PD_HIP(ctx, hipMemcpyAsync(ctx->ms_dev, ctx->ms_dev_image, sizeof(ms), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
     return PD_OK;
 }
 

@@ -157,6 +157,17 @@ struct pd_ctx {
     const float* ms_paf[PD_MAX_SCALES];   // (B, hs, ws, 38)
     int32_t ms_hs[PD_MAX_SCALES], ms_ws[PD_MAX_SCALES], ms_crop_h[PD_MAX_SCALES], ms_crop_w[PD_MAX_SCALES];
     int ms_heat_full;  // the heat average of the current source has been written to full_heat
+    void* ms_dev;      // device copy of the MultiSource (for the kernel that takes it by address)
+    unsigned char ms_dev_image[640];  // what ms_dev holds
+    // sparse peak stage of a multi-scale source: composite weights in cell form, planar copies of the heatmaps
+    int msf_ok;
+    int msf_key[3 + 4 * PD_MAX_SCALES];  // the geometry the tables were built for
+    float* msf_tab;
+    int32_t* msf_lo;
+    size_t msf_tab_cap, msf_lo_cap;      // in bytes
+    int msf_lds_a, msf_lds_r;            // floats of the bound kernel's staging areas
+    float* ms_planar;                    // per scale (B, 18, hs, ws) float32
+    size_t ms_planar_cap;
     void* tmp_in;  // staging for host-resident full-resolution input
     size_t tmp_in_cap;
     double* tmp_smooth;  // (B, 18, H, W) scratch of the simple path / debug hook

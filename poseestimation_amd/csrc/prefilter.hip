@@ -39,18 +39,10 @@
 #include <vector>
 
 #include "colloader.h"
+#include "prefilter.h"
 
 #pragma clang fp contract(off)
 
-#define KF_CELLS_PER_WAVE 6   // ten lanes per cell
-#define KF_CELLS_PER_BLOCK 24
-#define KF_LCAND 512          // candidates staged in LDS per workgroup between flushes
-#define KF_OVERFLOW (1 << 30)  // or-ed into a plane's candidate count: more than any list length
-// The cell list and the candidate list are filled by thousands of workgroups.  Atomics
-// on one address serialise chip-wide (tens of nanoseconds each), so each list is split
-// into KF_NSEG segments with a counter of their own; readers rebuild the global order
-// from the 32 counts.
-#define KF_NSEG 32
 
 static const double h_gw[PD_GTAPS] = PD_GAUSS_WEIGHTS;
 
@@ -248,13 +240,6 @@ k_heat_planar(const float* __restrict__ lo, int npix, float* __restrict__ planar
         for (int i = tid; i < np; i += 256) dst[(size_t)c * npix + i] = tile[i * PD_CH_HEAT + c];
 }
 
-// Lower threshold and neighbour slack of the candidate test for an image whose
-// heatmaps are bounded by absmax.
-__device__ __forceinline__ void filter_slack(double thr, float absmax, float* thr_lo, float* e2) {
-    const double eps = ldexp((double)absmax, -17);
-    *thr_lo = nextafterf((float)(thr - eps), -INFINITY);
-    *e2 = nextafterf((float)(2.0 * eps), INFINITY);
-}
 
 // ---------------------------------------------------------------------------------
 // Active cells: one workgroup per (part, image) plane.
@@ -460,31 +445,6 @@ struct CellFilterArgs {
     int CK;
 };
 
-// Exclusive prefix of the segment counts (each clipped to the segment capacity) into
-// pref[0 .. KF_NSEG]; call with all threads, ends with a barrier.
-__device__ __forceinline__ void segment_prefix(const int32_t* counts, int seg_cap, int* pref, int tid) {
-    if (tid < 64) {
-        int c = tid < KF_NSEG ? min(counts[tid], seg_cap) : 0;
-        int incl = c;
-#pragma unroll
-        for (int d = 1; d < KF_NSEG; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (tid >= d) incl += o;
-        }
-        if (tid < KF_NSEG) pref[tid + 1] = incl;
-        if (tid == 0) pref[0] = 0;
-    }
-    __syncthreads();
-}
-
-// Global index -> position in the segmented array (segment * seg_cap + offset).
-__device__ __forceinline__ int segment_locate(const int* pref, int seg_cap, int gi) {
-    int seg = 0;
-#pragma unroll
-    for (int d = KF_NSEG / 2; d >= 1; d >>= 1)
-        if (pref[seg + d] <= gi) seg += d;
-    return seg * seg_cap + (gi - pref[seg]);
-}
 
 template <int LCAND, int WSLOTS>
 struct FilterSharedT {
@@ -1163,7 +1123,9 @@ k_verify(VerifyArgs a) {
     }
 }
 
-static int grow(pd_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
+
+
+int pd_grow(pd_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
     if (*cap >= need_bytes) return PD_OK;
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->gen++;
@@ -1176,7 +1138,7 @@ static int grow(pd_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
 }
 
 // The candidate list: room for CK = 4 * max_peaks_per_part entries per plane.
-static int ensure_candidates(pd_ctx* ctx, int* CK_out) {
+int pd_ensure_candidates(pd_ctx* ctx, int* CK_out) {
     const int CK = 4 * ctx->cfg.max_peaks_per_part;
     const size_t planes_max = (size_t)ctx->cfg.max_batch * PD_N_PARTS;
     if (planes_max >= (1u << 17)) return PD_E_STATE;  // plane index is packed in 17 bits
@@ -1198,15 +1160,15 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     const int B = ctx->B, H = ctx->H, W = ctx->W, h = ctx->h, w = ctx->w;
     const int hc = (H + 7) / 8, wc = (W + 7) / 8;
     int CK = 0;
-    rc = ensure_candidates(ctx, &CK);
+    rc = pd_ensure_candidates(ctx, &CK);
     if (rc != PD_OK) return rc;
-    rc = grow(ctx, (void**)&ctx->heat_planar, &ctx->heat_planar_cap, sizeof(float) * (size_t)B * PD_CH_HEAT * h * w);
+    rc = pd_grow(ctx, (void**)&ctx->heat_planar, &ctx->heat_planar_cap, sizeof(float) * (size_t)B * PD_CH_HEAT * h * w);
     if (rc != PD_OK) return rc;
     const size_t planes = (size_t)B * PD_N_PARTS;
     const size_t n_cells_max = planes * hc * wc;
     // a segment holds the cells of the planes p with p % KF_NSEG == its index
     const size_t seg_cap = ((planes + KF_NSEG - 1) / KF_NSEG) * hc * wc;
-    rc = grow(ctx, (void**)&ctx->cells, &ctx->cells_cap, sizeof(int32_t) * seg_cap * KF_NSEG);
+    rc = pd_grow(ctx, (void**)&ctx->cells, &ctx->cells_cap, sizeof(int32_t) * seg_cap * KF_NSEG);
     if (rc != PD_OK) return rc;
     // counters behind the per-plane candidate counts, KF_NSEG each: candidates, interior cells, border cells
     int32_t* counters = ctx->cand_count + planes;
@@ -1545,7 +1507,7 @@ int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr) {
     const int B = ctx->B, H = ctx->H, W = ctx->W;
     if (H >= 65536 || W >= 65536) return PD_E_STATE;  // candidates pack (y, x) in 16 bits each
     int CK = 0;
-    int rc = ensure_candidates(ctx, &CK);
+    int rc = pd_ensure_candidates(ctx, &CK);
     if (rc != PD_OK) return rc;
     const size_t planes = (size_t)B * PD_N_PARTS;
     int32_t* counters = ctx->cand_count + planes;

@@ -31,6 +31,38 @@ struct SmoothArgs {
     SortArgs sort;  // k_finish_peaks: what the ordering of the peaks needs
 };
 
+// What a multi-scale source adds: the scales (a kernel argument of their own) and the x8 weights
+// by phase in LDS.
+#define PD_MULTI_REF const MultiSource *ms, const float4 *up8
+
+// Column of the average over the scales of a multi-scale source, evaluated pixel by pixel from
+// the network outputs (the two-step bicubic of every scale, its float32 share, the float64 sum).
+// Only planes whose candidate list overflowed come this way.
+template <>
+struct ColLoader<PD_SRC_MULTI> {
+    const MultiSource* ms;
+    const float4* up;
+    int b, ch, col;
+    __device__ __forceinline__ void init(const MapSource&, int b_, int ch_, int c) {
+        b = b_;
+        ch = ch_;
+        col = c;
+    }
+    __device__ __forceinline__ double load(int r) const {
+        double acc[1];
+        pd_ms_avg_at<1>(*ms, false, b, ch, r, col, up, acc);
+        return acc[0];
+    }
+};
+
+template <int SRC>
+__device__ __forceinline__ void loader_attach(ColLoader<SRC>&, PD_MULTI_REF) {}
+template <>
+__device__ __forceinline__ void loader_attach<PD_SRC_MULTI>(ColLoader<PD_SRC_MULTI>& ld, PD_MULTI_REF) {
+    ld.ms = ms;
+    ld.up = up8;
+}
+
 __device__ __forceinline__ void emit_peak(bool is_peak, int y, int x, double score, RawPeak* list,
                                           int32_t* count, int PK) {
     const unsigned long long m = __ballot(is_peak);
@@ -120,7 +152,8 @@ __device__ __forceinline__ void row_step(const SmoothArgs& a, ColLoader<SRC>& ld
 }
 
 template <int SRC>
-__device__ __forceinline__ void stream_plane(const SmoothArgs& a, double* ybuf, double* sbuf, int b, int part, int strip);
+__device__ __forceinline__ void stream_plane(const SmoothArgs& a, double* ybuf, double* sbuf, int b, int part, int strip,
+                                             const MultiSource* ms = nullptr, const float4* up8 = nullptr);
 
 template <int SRC>
 __global__ void __launch_bounds__(NTMAX)
@@ -137,8 +170,7 @@ k_smooth_nms_stream(SmoothArgs a) {
 // then the image's peaks are ordered.  Everything an image needs is written and read by its
 // own workgroup, so barriers are all the synchronisation there is.
 template <int SRC>
-__global__ void __launch_bounds__(NTMAX)
-k_finish_peaks(SmoothArgs a) {
+__device__ __forceinline__ void finish_peaks_body(const SmoothArgs& a, PD_MULTI_REF) {
     __shared__ double ybuf[2 * (NTMAX + 2 * PD_GR)];
     __shared__ double sbuf[2 * (NTMAX + 2)];
     __shared__ SortShared s_sort;
@@ -147,7 +179,7 @@ k_finish_peaks(SmoothArgs a) {
         if (a.only_over[b * PD_N_PARTS + part] <= a.over_limit) continue;  // uniform over the workgroup
         for (int strip = 0; strip < a.n_strips; ++strip) {
             __syncthreads();
-            stream_plane<SRC>(a, ybuf, sbuf, b, part, strip);
+            stream_plane<SRC>(a, ybuf, sbuf, b, part, strip, ms, up8);
         }
     }
     __syncthreads();
@@ -155,7 +187,25 @@ k_finish_peaks(SmoothArgs a) {
 }
 
 template <int SRC>
-__device__ __forceinline__ void stream_plane(const SmoothArgs& a, double* ybuf, double* sbuf, int b, int part, int strip) {
+__global__ void __launch_bounds__(NTMAX)
+k_finish_peaks(SmoothArgs a) {
+    finish_peaks_body<SRC>(a, nullptr, nullptr);
+}
+
+__global__ void __launch_bounds__(NTMAX)
+k_finish_peaks_ms(SmoothArgs a, const MultiSource* __restrict__ ms) {
+    __shared__ float4 s_up8[8];
+    if (threadIdx.x < 8) {
+        const float* c = a.src.up8.c[threadIdx.x];
+        s_up8[threadIdx.x] = make_float4(c[0], c[1], c[2], c[3]);
+    }
+    __syncthreads();
+    finish_peaks_body<PD_SRC_MULTI>(a, ms, s_up8);
+}
+
+template <int SRC>
+__device__ __forceinline__ void stream_plane(const SmoothArgs& a, double* ybuf, double* sbuf, int b, int part, int strip,
+                                             PD_MULTI_REF) {
     const int H = a.src.H, W = a.src.W;
     const int x0 = strip * a.strip_w;
     const int x1 = min(W, x0 + a.strip_w);
@@ -172,6 +222,7 @@ __device__ __forceinline__ void stream_plane(const SmoothArgs& a, double* ybuf, 
     double* dbg_plane = a.dbg ? a.dbg + ((size_t)b * PD_N_PARTS + part) * (size_t)H * W : nullptr;
 
     ColLoader<SRC> ld;
+    loader_attach<SRC>(ld, ms, up8);
     if (col_active) ld.init(a.src, b, part, c);
     double win[25];
 #pragma unroll
@@ -314,6 +365,17 @@ int pd_launch_stream_exact(pd_ctx* ctx, double thr, int f32mode, double* dbg_smo
     a.only_over = only_over;
     a.over_limit = over_limit;
     memset(&a.sort, 0, sizeof(a.sort));
+    if (src.kind == PD_SRC_MULTI) {
+        // only as the end of the sparse multi-scale peak stage (overflowing planes + ordering)
+        if (!(finish && only_over != nullptr && dbg_smoothed == nullptr)) PD_FAIL(ctx, PD_E_STATE, "the exact kernel over every pixel needs stored maps");
+        pd_fill_sort_args(ctx, &a.sort);
+        ctx->peaks_sorted = 1;
+        pd_prof_begin(ctx, PD_STAGE_SMOOTH_NMS);
+        hipLaunchKernelGGL(k_finish_peaks_ms, dim3(ctx->B), dim3(nt), 0, ctx->stream, a, (const MultiSource*)ctx->ms_dev);
+        pd_prof_end(ctx);
+        PD_HIP(ctx, hipGetLastError());
+        return PD_OK;
+    }
     static const bool separate_sort = getenv("PD_SEPARATE_SORT") != nullptr;  // comparison runs
     if (finish && only_over != nullptr && dbg_smoothed == nullptr && !separate_sort) {
         pd_fill_sort_args(ctx, &a.sort);

@@ -608,3 +608,77 @@ def test_capacity_overflow_is_reported_not_truncated(pdec, caps):
     with pytest.raises(_ffi.DecodeOverflow):
         eng.decode_batch(heat, paf)
     eng.close()
+
+
+@pytest.mark.parametrize('kind', ['noise', 'large', 'flat', 'negative', 'border', 'plateau', 'one_scale_only'])
+def test_multiscale_sparse_peak_stage_equals_the_stored_maps_form(pdec, kind):
+    """The sparse multi-scale peak stage (cell bounds, float32 filter, exact verification from
+    the four sources) against the form that writes the float64 average out and runs the
+    full-resolution filter / exact kernel on it, on inputs built to break a tolerance or a
+    bound: noise of both signs, magnitudes of hundreds, a near-flat ridge just above the
+    threshold, maps below zero, maxima on the border rows and columns, plateaus (constant
+    sources: every pixel of a plateau is a peak, the candidate lists overflow and the exact
+    pass takes over) and scales that disagree."""
+    from poseestimation_amd import synth
+    H, W = 184, 200
+    scales = [0.5, 1.0, 1.5, 2.0]
+    rng = np.random.RandomState({'noise': 1, 'large': 2, 'flat': 3, 'negative': 4, 'border': 5, 'plateau': 6,
+                                 'one_scale_only': 7}[kind])
+    B = 2
+    heats, pafs, pads = [], [], []
+    for s in scales:
+        sh, sw = int(round(H * s)), int(round(W * s))
+        outs = [synth.scene(H, W, 2 + b, 800 + b, paf_order='xy', scale=s) for b in range(B)]
+        heat = np.stack([o[0] for o in outs])
+        paf = np.stack([o[1] for o in outs])
+        if kind == 'noise':
+            heat = heat + rng.randn(*heat.shape).astype(np.float32) * 0.2
+        elif kind == 'large':
+            heat = heat * 300 + rng.randn(*heat.shape).astype(np.float32) * 30
+        elif kind == 'flat':
+            heat = np.float32(0.1002) + rng.randn(*heat.shape).astype(np.float32) * 1e-5
+        elif kind == 'negative':
+            heat = -np.abs(heat) - 0.2
+        elif kind == 'border':
+            heat = heat * 0
+            heat[:, 0, :, :] = 1
+            heat[:, :, -1, :] = 1.5
+            heat[:, -1, 0, :] = 3
+        elif kind == 'plateau':
+            heat = np.full_like(heat, 0.5)
+            heat[:, :, : heat.shape[2] // 2, 3] = 0.0
+        elif kind == 'one_scale_only' and s != 1.5:
+            heat = heat * 0
+        heats.append(np.ascontiguousarray(heat, np.float32))
+        pafs.append(paf)
+        pads.append((heat.shape[1] * 8 - sh, heat.shape[2] * 8 - sw))
+    thr = 30.0 if kind == 'large' else 0.1
+    pk = 4096 if kind in ('plateau', 'flat') else 128
+    eng = pdec.DecodeEngine(B, H, W, mode='D', max_peaks_per_part=pk, max_pairs_per_image=16, max_persons=16)
+
+    def peaks_only(materialise):
+        if materialise:
+            eng.upsample_average(heats, pafs, pads, (H, W))
+        else:
+            sizes = [a.shape[1:3] for a in heats]
+            crops = [(a.shape[1] * 8 - p[0], a.shape[2] * 8 - p[1]) for a, p in zip(heats, pads)]
+            eng.ctx.set_multiscale([a.ctypes.data for a in heats], [a.ctypes.data for a in pafs], sizes, crops,
+                                   H, W, B, _ffi_mod().MEM_HOST)
+        eng.ctx.peaks(thr)
+        eng.ctx.pack()
+        return eng.ctx.fetch()
+
+    got = peaks_only(False)
+    want = peaks_only(True)
+    assert np.array_equal(got['part_count'], want['part_count'])
+    assert got['peaks'].tobytes() == want['peaks'].tobytes()
+    if kind in ('plateau', 'flat'):
+        assert want['part_count'].max() > 512        # more than any candidate list holds
+    if kind == 'border':
+        assert len(want['peaks']) > 0
+    eng.close()
+
+
+def _ffi_mod():
+    from poseestimation_amd import _ffi
+    return _ffi
