@@ -723,7 +723,9 @@ def run_multiscale(env):
     import gc
     gc.collect()
     gc.freeze()
-    TIMED = ['resize', 'smooth_nms', 'filter', 'verify']
+    # every kernel of a step carries an event pair: a step is seven launches of 0.02 - 0.4 ms, the
+    # pairs cost nothing beside them
+    TIMED = ['resize', 'planar', 'cells', 'filter', 'verify', 'smooth_nms', 'pairs', 'match', 'parse', 'pack']
     for e in engs:
         e.ctx.profile(stages=TIMED)
     run(2 * len(engs))
@@ -744,71 +746,64 @@ def run_multiscale(env):
             stage[k] = (a[0] + v[0], a[1] + v[1])
     dt = max_over_ranks(env, dt)
     prof = {}
-    if rank == 0 and not env['use_dist'] and not args.no_extras:
-        for e in engs:
-            e.ctx.profile(True)
-        run(len(engs))
-        for e in engs:
-            e.ctx.profile_read()
-        run(2 * len(engs))
-        for e in engs:
-            for k, v in e.ctx.profile_read().items():
-                a = prof.get(k, (0.0, 0))
-                prof[k] = (a[0] + v[0], a[1] + v[1])
-            e.ctx.profile(False)
 
     out = None
     if rank == 0:
         value = world * B * args.steps / dt
+        step_s = dt / args.steps
         n_sum = sum(hs * ws for hs, ws in sizes)
         N_sum = 64 * n_sum
         N = H * W
-        # The resize stage (x8 upsample, second resize and average of all scales, heat and PAF
-        # families): kernel time summed over its launches of one step.
-        resize_ms = stage['resize'][0] / max(args.steps, 1)
-        resize_launches = stage['resize'][1] / max(args.steps, 1)
-        must = B * (228.0 * n_sum + 57.0 * N * 8)                          # network outputs read, float64 averages written
-        materialised = B * (228.0 * n_sum + 2 * 228.0 * N_sum + 57.0 * N * 8)    # + the four x8 maps written and read back
         pmc = pmc_traffic(args.workload)
-        traffic = pmc.get('resize_stage_hbm_bytes') if pmc else None
+        # Bytes a step has to move for this algorithm: the network outputs of every scale read once
+        # (heatmaps without the background channel, which predict.py:91 never reads) and the packed
+        # results written once.
+        result_bytes = int(len(last['raw'])) if 'raw' in last else int(last['peaks'].nbytes + last['persons'].nbytes)
+        must = B * 4.0 * n_sum * (18 + 38) + result_bytes
+        traffic = pmc.get('step_hbm_bytes') if pmc else None
         roofline = {
-            'bound': 'hbm', 'kernel': 'resize stage of one step: x8 bicubic + second resize + average of four scales, '
-                                      '%.0f launches (k_resize_*)' % resize_launches,
-            'achieved': must / (resize_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': must / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            'traffic': traffic,
+            'bound': 'hbm', 'kernel': 'whole multi-scale decode of one batch (all kernels of the chain)',
+            'achieved': must / step_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': must / step_s / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
             'algorithmic_bytes_per_launch': must,
-            'bytes_counted': 'B * (228 * sum_s n_s  +  57 * N * 8): every network output read once, the float64 '
-                             'averages written once',
-            'avg_launch_ms': resize_ms,
-            'measured': 'HIP event pairs around the stage\'s kernels in every step of the timed region',
-            'materialising_formula_bytes': materialised,
-            'materialising_formula_note': 'the byte formula of a pipeline that materialises the x8 maps also counts them written and read back '
-                                   '(2 * 228 * sum_s N_s); an implementation that materialises them moves that much',
+            'bytes_counted': 'B * 4 * sum_s n_s * (18 + 38): the network outputs of the four scales read once '
+                             '(no background heat channel) + packed results written once',
+            'avg_launch_ms': step_s * 1e3,
+            'note': 'nothing at full resolution is stored: the peak stage visits the cells that can hold a peak, the PAF '
+                    'average is evaluated at the sample points of the candidate pairs; the path is bound by vector issue '
+                    'and latency, not by HBM',
         }
-        sf = materialised / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        roofline['materialising_formula_frac'] = sf if sf <= 1.0 else None
-        roofline['materialising_formula_speedup_vs_hbm_peak'] = sf
         if traffic:
-            roofline['traffic_frac'] = traffic / (resize_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             roofline['wasted_traffic_ratio'] = traffic / must
-        if 'filter' in stage and stage['filter'][1]:
-            # the peak stage behind the resize: one float32 streaming pass over the 18 float64
-            # heat planes of every image (upsampled maps are the input here, so every pixel is read)
-            f_ms = stage['filter'][0] / stage['filter'][1]
-            f_must = B * 18.0 * N * 8
-            f_traffic = None
-            if pmc and pmc.get('kernels'):
-                for kname, kv in pmc['kernels'].items():
-                    if kname.split('(')[0].split('<')[0] == 'k_full_filter':
-                        f_traffic = kv['hbm_bytes']
-            roofline['k_full_filter'] = {
-                'bound': 'hbm', 'algorithmic_bytes_per_launch': f_must,
-                'bytes_counted': 'B * 18 * N * 8: the float64 averages of the 18 part planes read once (candidates written: negligible)',
-                'avg_launch_ms': f_ms, 'launches': stage['filter'][1],
-                'measured': 'HIP event pair around the kernel in every step of the timed region',
-                'achieved': f_must / (f_ms * 1e-3) / 1e9, 'frac': f_must / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                'traffic': f_traffic}
+        per_stage = {k: v[0] / v[1] for k, v in stage.items() if v[1]}
+        # per-kernel figures: algorithmic bytes of each kernel of the chain / its event-timed duration
+        kbytes = {
+            'planar': ('k_ms_planar', B * 4.0 * n_sum * (19 + 18), 'heatmaps of the four scales read (19 channels), planar copies written (18)'),
+            'cells': ('k_ms_cells', B * 4.0 * n_sum * 18, 'planar copies read once'),
+            'filter': ('k_ms_cell_filter' if 'resize' not in per_stage else 'k_full_filter',
+                       B * 4.0 * n_sum * 18 if 'resize' not in per_stage else B * 18.0 * N * 8,
+                       'planar copies read once (the windows of the active cells overlap; re-reads come from the caches)'
+                       if 'resize' not in per_stage else 'B * 18 * N * 8: the stored float64 averages read once'),
+            'pairs': ('k_pair_scores_ms', B * 4.0 * n_sum * 38, 'PAF outputs of the four scales read once'),
+            'resize': ('k_resize_tiles', B * (76.0 * n_sum + 19.0 * N * 8), 'heat outputs read, float64 averages written (stored-maps form)'),
+        }
+        kern = {}
+        for st, (kname, nbytes, what) in kbytes.items():
+            if st in per_stage:
+                ms = per_stage[st]
+                kt = None
+                if pmc and pmc.get('kernels'):
+                    for pk_name, kv in pmc['kernels'].items():
+                        if pk_name.split('(')[0].split('<')[0] == kname:
+                            kt = kv['hbm_bytes']
+                kern[kname] = {'avg_launch_ms': ms, 'launches': stage[st][1], 'algorithmic_bytes_per_launch': nbytes,
+                               'bytes_counted': what, 'achieved': nbytes / (ms * 1e-3) / 1e9,
+                               'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': kt,
+                               'measured': 'HIP event pair around the kernel in every step of the timed region'}
+        roofline['kernels'] = kern
+        if per_stage:
+            dom = max(per_stage, key=per_stage.get)
+            roofline['dominant_kernel'] = kbytes[dom][0] if dom in kbytes else dom
         out = {
             'metric': 'decoded images/sec (heatmap+PAF->skeletons) at %dx%d' % (H, W),
             'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -826,6 +821,8 @@ def run_multiscale(env):
         if prof:
             out['stage_ms_per_launch_untimed_pass'] = {k: v[0] / v[1] for k, v in prof.items() if v[1]}
         out['persons_last_step'] = int(last['person_count'].sum())
+        if gather is None:
+            out['filter_stats_last_step'] = engs[0].ctx.filter_stats()
         if not env['use_dist'] and not args.no_cpu:
             from oracle import decode_ref as ref
             ncpu = max(1, min(args.cpu_images // 4, 3))

@@ -645,15 +645,16 @@ def test_multiscale_sparse_peak_stage_equals_the_stored_maps_form(pdec, kind):
             heat[:, :, -1, :] = 1.5
             heat[:, -1, 0, :] = 3
         elif kind == 'plateau':
-            heat = np.full_like(heat, 0.5)
-            heat[:, :, : heat.shape[2] // 2, 3] = 0.0
+            hh, ww = heat.shape[1:3]
+            heat = heat * 0
+            heat[:, int(0.2 * hh):int(0.55 * hh), int(0.25 * ww):int(0.6 * ww), 3] = 0.5
         elif kind == 'one_scale_only' and s != 1.5:
             heat = heat * 0
         heats.append(np.ascontiguousarray(heat, np.float32))
         pafs.append(paf)
         pads.append((heat.shape[1] * 8 - sh, heat.shape[2] * 8 - sw))
     thr = 30.0 if kind == 'large' else 0.1
-    pk = 4096 if kind in ('plateau', 'flat') else 128
+    pk = 4096
     eng = pdec.DecodeEngine(B, H, W, mode='D', max_peaks_per_part=pk, max_pairs_per_image=16, max_persons=16)
 
     def peaks_only(materialise):
@@ -669,12 +670,13 @@ def test_multiscale_sparse_peak_stage_equals_the_stored_maps_form(pdec, kind):
         return eng.ctx.fetch()
 
     got = peaks_only(False)
+    stats = eng.ctx.filter_stats()
     want = peaks_only(True)
     assert np.array_equal(got['part_count'], want['part_count'])
     assert got['peaks'].tobytes() == want['peaks'].tobytes()
-    if kind in ('plateau', 'flat'):
-        assert want['part_count'].max() > 512        # more than any candidate list holds
-    if kind == 'border':
+    if kind == 'flat':
+        assert stats['planes_exact'] > 0             # candidate lists overflowed: the exact pass redid those planes
+    if kind in ('border', 'plateau'):
         assert len(want['peaks']) > 0
     eng.close()
 
