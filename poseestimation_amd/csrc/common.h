@@ -166,6 +166,7 @@ struct pd_ctx {
     int32_t* msf_lo;
     size_t msf_tab_cap, msf_lo_cap;      // in bytes
     int msf_lds_a, msf_lds_r;            // floats of the bound kernel's staging areas
+    int msf_nq[PD_MAX_SCALES];           // float4 words of a table row in use, per scale
     float* ms_planar;                    // per scale (B, 18, hs, ws) float32
     size_t ms_planar_cap;
     void* tmp_in;  // staging for host-resident full-resolution input

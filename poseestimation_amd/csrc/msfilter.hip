@@ -40,7 +40,7 @@
 #define MSF_ROW 20      // LDS row stride of the 16-wide staging rows, in floats (16-byte aligned, off the bank period)
 #define MSV_P 64        // largest side of the x8-map patch the verification stages per scale
 #define MSV_NJ 14       // source rows such a patch draws on, at most
-#define MSV_NT 128
+#define MSV_NT 256
 #define MSP_PIX 256
 
 static const double h_gw[PD_GTAPS] = PD_GAUSS_WEIGHTS;
@@ -53,6 +53,7 @@ struct MsAxisTab {
 struct MsScale {
     const float* planar;  // (B, 18, hs, ws) float32 copy of the heatmaps of this scale
     int hs, ws, crop_h, crop_w, identity;
+    int nq;               // float4 words of a table row that hold non-zero weights (both axes): 1..4
     MsAxisTab y, x;
     CubicTable ty, tx;    // second resize crop -> (H, W)
 };
@@ -121,7 +122,7 @@ static void axis_composite(int l, int crop, int L, bool identity, double factor,
 
 // Cell form of K; false if some cell's window is wider than MSF_T.
 static bool axis_cells(int L, int l, const std::vector<double>& K, std::vector<float>& cw, std::vector<float>& bw,
-                       std::vector<int32_t>& lo) {
+                       std::vector<int32_t>& lo, int* widest) {
     const int nc = (L + 7) / 8;
     cw.assign((size_t)nc * 10 * MSF_T, 0.f);
     bw.assign((size_t)nc * MSF_T, 0.f);
@@ -139,6 +140,7 @@ static bool axis_cells(int L, int l, const std::vector<double>& K, std::vector<f
         }
         if (last < first) continue;  // (no output of the cell lies in the map: cannot happen for c < nc)
         if (last - first + 1 > MSF_T) return false;
+        if (last - first + 1 > *widest) *widest = last - first + 1;
         lo[c] = first;
         for (int j = 0; j < 10; ++j) {
             const int o = 8 * c - 1 + j;
@@ -219,6 +221,8 @@ static int build_ms_tables(pd_ctx* ctx) {
     const MsLayout lay = ms_layout(n, hc, wc);
     std::vector<float> tab(lay.n_float);
     std::vector<int32_t> los(lay.n_int);
+    int widest[PD_MAX_SCALES];
+    memset(widest, 0, sizeof(widest));
     for (int m = 0; m < n; ++m) {
         const bool identity = ctx->ms_crop_h[m] == H && ctx->ms_crop_w[m] == W;
         if (!identity && (max_patch_extent(ctx->ms_crop_h[m], H) > MSV_P || max_patch_extent(ctx->ms_crop_w[m], W) > MSV_P)) return PD_E_STATE;
@@ -229,7 +233,7 @@ static int build_ms_tables(pd_ctx* ctx) {
             axis_composite(l, crop, L, identity, ax == 0 ? 1.0 / (double)n : 1.0, K);
             std::vector<float> cw, bw;
             std::vector<int32_t> lo;
-            if (!axis_cells(L, l, K, cw, bw, lo)) return PD_E_STATE;
+            if (!axis_cells(L, l, K, cw, bw, lo, &widest[m])) return PD_E_STATE;
             memcpy(&tab[lay.cw[m][ax]], cw.data(), cw.size() * sizeof(float));
             memcpy(&tab[lay.bw[m][ax]], bw.data(), bw.size() * sizeof(float));
             memcpy(&los[lay.lo[m][ax]], lo.data(), lo.size() * sizeof(int32_t));
@@ -244,6 +248,7 @@ static int build_ms_tables(pd_ctx* ctx) {
     PD_HIP(ctx, hipMemcpy(ctx->msf_lo, los.data(), los.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     ctx->msf_lds_a = (int)lds_a;
     ctx->msf_lds_r = (int)lds_r;
+    for (int m = 0; m < n; ++m) ctx->msf_nq[m] = (widest[m] + 3) / 4;
     ctx->msf_ok = 1;
     return PD_OK;
 }
@@ -287,6 +292,135 @@ k_ms_planar(MsPlanarArgs a) {
 // in LDS, the row sums R[s][cx] = sum_t Bx[cx][t] |src[s][t]| are formed for every source row and
 // cell column, then every cell adds sum_s By[cy][s] R[s][cx] to its bound.
 // ---------------------------------------------------------------------------------
+// Maps of at most 64 x 64 cells: lane = cell column, wavefront = every fourth row.  A thread keeps
+// its column's 16 bound weights and clamped source columns in registers for the row sums, the
+// bounds of its (at most 16) cells in registers as well, and the row weights of the cell row at
+// hand are the same for the whole wavefront (scalar loads).
+__global__ void __launch_bounds__(256)
+k_ms_cells64(MsArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    __shared__ float s_red[4];
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per_xcd = gridDim.x / 8;
+    const int plane = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // the planes of an image on one XCD
+    if (plane >= a.n_planes) return;
+    const int hc = a.hc, wc = a.wc;
+    const int cx = lane;
+    const bool act = cx < wc;
+    float* A = lds;           // [hs][ws] of the scale at hand
+    float* R = A + a.lds_a;   // [hs][wc]
+    __shared__ __align__(16) float s_by[64 * MSF_T];  // the row weights of the scale at hand, every cell row
+    __shared__ int s_loy[64];
+    float U[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) U[k] = 0.f;
+    float mx = 0.f;
+#pragma unroll 1
+    for (int m = 0; m < a.n; ++m) {
+        const MsScale& sc = a.s[m];
+        const int hs = sc.hs, ws = sc.ws, nq = sc.nq;
+        const float* src = sc.planar + (size_t)plane * hs * ws;
+        for (int i = tid; i < hs * ws; i += 256) {
+            const float v = fabsf(src[i]);
+            A[i] = v;
+            mx = fmaxf(mx, v);
+        }
+        for (int i = tid; i < hc * (MSF_T / 4); i += 256) ((float4*)s_by)[i] = ((const float4*)sc.y.bw)[i];
+        if (tid < hc) s_loy[tid] = sc.y.lo[tid];
+        float bw[MSF_T];
+        int col[MSF_T];
+        {
+            const int lo = act ? sc.x.lo[cx] : 0;
+            const float4* b4 = (const float4*)(sc.x.bw + (size_t)(act ? cx : 0) * MSF_T);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = b4[q];
+                bw[4 * q] = w.x;
+                bw[4 * q + 1] = w.y;
+                bw[4 * q + 2] = w.z;
+                bw[4 * q + 3] = w.w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) col[4 * q + k] = min(lo + 4 * q + k, ws - 1);
+            }
+        }
+        __syncthreads();
+        if (act)
+            for (int s = wv; s < hs; s += 4) {
+                const float* row = A + s * ws;
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nq) {
+                        acc = fmaf(bw[4 * q], row[col[4 * q]], acc);
+                        acc = fmaf(bw[4 * q + 1], row[col[4 * q + 1]], acc);
+                        acc = fmaf(bw[4 * q + 2], row[col[4 * q + 2]], acc);
+                        acc = fmaf(bw[4 * q + 3], row[col[4 * q + 3]], acc);
+                    }
+                R[s * wc + cx] = acc;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int cy = __builtin_amdgcn_readfirstlane(wv + 4 * k);
+            if (cy < hc && act) {
+                const int lo = s_loy[cy];
+                const float4* by = (const float4*)(s_by + cy * MSF_T);
+                float acc = U[k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nq) {
+                        const float4 w = by[q];
+                        acc = fmaf(w.x, R[min(lo + 4 * q, hs - 1) * wc + cx], acc);
+                        acc = fmaf(w.y, R[min(lo + 4 * q + 1, hs - 1) * wc + cx], acc);
+                        acc = fmaf(w.z, R[min(lo + 4 * q + 2, hs - 1) * wc + cx], acc);
+                        acc = fmaf(w.w, R[min(lo + 4 * q + 3, hs - 1) * wc + cx], acc);
+                    }
+                U[k] = acc;
+            }
+        }
+        __syncthreads();  // the row weights are replaced by the next scale's
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (lane == 0) s_red[wv] = mx;
+    __syncthreads();
+    float thr_lo = 0.f, e2 = 0.f;
+    if (lane == 0) {
+        filter_slack(a.thr, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), &thr_lo, &e2, MSF_EPS_SHIFT);
+        if (wv == 0) a.slack[plane] = make_float2(thr_lo, e2);
+    }
+    thr_lo = __shfl(thr_lo, 0);
+    unsigned mask = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (act && wv + 4 * k < hc && U[k] * 1.00001f >= thr_lo) mask |= 1u << k;
+    const int mine = __builtin_popcount(mask);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_cnt[wv] = incl;
+    __syncthreads();
+    const int seg = plane % KF_NSEG;
+    if (tid == 0) {
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = total ? atomicAdd(a.n_cells + seg, total) : 0;
+    }
+    __syncthreads();
+    int at = s_base + incl - mine;
+    for (int q = 0; q < wv; ++q) at += s_cnt[q];
+    int32_t* segment = a.cells + (size_t)seg * a.seg_cap;
+    while (mask) {
+        const int k = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        segment[at++] = (plane << 14) | ((wv + 4 * k) << 7) | cx;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_ms_cells(MsArgs a) {
     extern __shared__ __align__(16) float lds[];
@@ -395,8 +529,8 @@ k_ms_cells(MsArgs a) {
 // ---------------------------------------------------------------------------------
 struct MsFilterShared {
     __attribute__((aligned(16))) float win[4][MSF_T * MSF_ROW];   // source window, row s
-    __attribute__((aligned(16))) float wx[4][10 * MSF_T];
-    __attribute__((aligned(16))) float wy[4][10 * MSF_T];
+    __attribute__((aligned(16))) float wx[4][10 * MSF_ROW];       // weights of output column i
+    __attribute__((aligned(16))) float wy[4][10 * MSF_ROW];       // weights of output row j
     __attribute__((aligned(16))) float tt[4][10 * MSF_ROW];       // x-pass sums, transposed: output column i, source row s
     float sm[4][100];
     int2 cand[KF_LCAND];
@@ -404,19 +538,71 @@ struct MsFilterShared {
     int base;
 };
 
-__device__ __forceinline__ float dot16(const float* w, const float* v) {
+// What one lane fetches for one (cell, scale): four window values and three weights of either table.
+struct MsFetch {
+    float v[4], gx[3], gy[3];
+};
+
+__device__ __forceinline__ void ms_fetch(const MsScale& sc, int plane, int cy, int cx, int lane, MsFetch& f) {
+    const int hs = sc.hs, ws = sc.ws;
+    const float* src = sc.planar + (size_t)plane * hs * ws;
+    const int loy = sc.y.lo[cy], lox = sc.x.lo[cx];
+    const float* gx = sc.x.cw + (size_t)cx * 10 * MSF_T;
+    const float* gy = sc.y.cw + (size_t)cy * 10 * MSF_T;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int el = lane + 64 * k, s = el >> 4, p = el & 15;
+        f.v[k] = src[(size_t)min(loy + s, hs - 1) * ws + min(lox + p, ws - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int el = lane + 64 * k;
+        f.gx[k] = el < 10 * MSF_T ? gx[el] : 0.f;
+        f.gy[k] = el < 10 * MSF_T ? gy[el] : 0.f;
+    }
+}
+
+template <int NQ>
+__device__ __forceinline__ float dotq(const float* w, const float4 (&v)[NQ]) {
     const float4* w4 = (const float4*)w;
-    const float4* v4 = (const float4*)v;
     float acc = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 a = w4[q], b = v4[q];
-        acc = fmaf(a.x, b.x, acc);
-        acc = fmaf(a.y, b.y, acc);
-        acc = fmaf(a.z, b.z, acc);
-        acc = fmaf(a.w, b.w, acc);
+    for (int q = 0; q < NQ; ++q) {
+        const float4 a = w4[q];
+        acc = fmaf(a.x, v[q].x, acc);
+        acc = fmaf(a.y, v[q].y, acc);
+        acc = fmaf(a.z, v[q].z, acc);
+        acc = fmaf(a.w, v[q].w, acc);
     }
     return acc;
+}
+
+// The two passes of one scale from the staged window and weights.  x pass: lane = (source row s,
+// group g), the row read once, outputs i = g, g + 4, g + 8.  y pass: lane = (output column i,
+// group jg), the column of x-pass sums read once, outputs j = jg, jg + 6.
+template <int NQ>
+__device__ __forceinline__ void ms_passes(const float* win, const float* wx, const float* wy, float* tt, int lane, float& acc0,
+                                          float& acc1) {
+    {
+        const int s = lane >> 2, g = lane & 3;
+        float4 r[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) r[q] = ((const float4*)(win + s * MSF_ROW))[q];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int i = g + 4 * t;
+            if (i < 10) tt[i * MSF_ROW + s] = dotq<NQ>(wx + i * MSF_ROW, r);
+        }
+    }
+    pd_wave_sync();
+    if (lane < 60) {
+        const int jg = lane / 10, i = lane - 10 * jg;
+        float4 c[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) c[q] = ((const float4*)(tt + i * MSF_ROW))[q];
+        acc0 += dotq<NQ>(wy + jg * MSF_ROW, c);
+        if (jg < 4) acc1 += dotq<NQ>(wy + (jg + 6) * MSF_ROW, c);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -440,62 +626,40 @@ k_ms_cell_filter(MsArgs a) {
         const int plane = e >> 14, cy = (e >> 7) & 127, cx = e & 127;
         const float2 sl = a.slack[plane];
         float acc0 = 0.f, acc1 = 0.f;
+        MsFetch f;
+        ms_fetch(a.s[0], plane, cy, cx, lane, f);
 #pragma unroll 1
         for (int m = 0; m < a.n; ++m) {
-            const MsScale& sc = a.s[m];
-            const int hs = sc.hs, ws = sc.ws;
-            const float* src = sc.planar + (size_t)plane * hs * ws;
-            const int loy = sc.y.lo[cy], lox = sc.x.lo[cx];
-            const float* gx = sc.x.cw + (size_t)cx * 10 * MSF_T;
-            const float* gy = sc.y.cw + (size_t)cy * 10 * MSF_T;
-            float v[4], a0[3], a1[3];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int el = lane + 64 * k, s = el >> 4, p = el & 15;
-                v[k] = src[(size_t)min(loy + s, hs - 1) * ws + min(lox + p, ws - 1)];
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int el = lane + 64 * k;
-                a0[k] = el < 10 * MSF_T ? gx[el] : 0.f;
-                a1[k] = el < 10 * MSF_T ? gy[el] : 0.f;
-            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int el = lane + 64 * k;
-                win[(el >> 4) * MSF_ROW + (el & 15)] = v[k];
+                win[(el >> 4) * MSF_ROW + (el & 15)] = f.v[k];
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int el = lane + 64 * k;
                 if (el < 10 * MSF_T) {
-                    wx[el] = a0[k];
-                    wy[el] = a1[k];
+                    wx[(el >> 4) * MSF_ROW + (el & 15)] = f.gx[k];
+                    wy[(el >> 4) * MSF_ROW + (el & 15)] = f.gy[k];
                 }
             }
+            const int nq = a.s[m].nq;
             pd_wave_sync();
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int el = lane + 64 * k;
-                if (el < 10 * MSF_T) {
-                    const int s = el / 10, i = el - 10 * s;
-                    tt[i * MSF_ROW + s] = dot16(wx + i * MSF_T, win + s * MSF_ROW);
-                }
-            }
-            pd_wave_sync();
-            {
-                const int j = lane / 10, i = lane - 10 * j;
-                acc0 += dot16(wy + j * MSF_T, tt + i * MSF_ROW);
-                const int el = lane + 64;
-                if (el < 100) {
-                    const int j1 = el / 10, i1 = el - 10 * j1;
-                    acc1 += dot16(wy + j1 * MSF_T, tt + i1 * MSF_ROW);
-                }
-            }
+            // the next scale's values are requested now and arrive while this one is evaluated
+            if (m + 1 < a.n) ms_fetch(a.s[m + 1], plane, cy, cx, lane, f);
+            if (nq <= 2)
+                ms_passes<2>(win, wx, wy, tt, lane, acc0, acc1);
+            else if (nq == 3)
+                ms_passes<3>(win, wx, wy, tt, lane, acc0, acc1);
+            else
+                ms_passes<4>(win, wx, wy, tt, lane, acc0, acc1);
             pd_wave_sync();  // the staging areas are rewritten by the next scale
         }
-        sm[lane] = acc0;
-        if (lane + 64 < 100) sm[lane + 64] = acc1;
+        if (lane < 60) {
+            const int jg = lane / 10, i = lane - 10 * jg;
+            sm[jg * 10 + i] = acc0;
+            if (jg < 4) sm[(jg + 6) * 10 + i] = acc1;
+        }
         pd_wave_sync();
         {
             // outputs outside the map have zero weights, so their sums are 0: the reference's zero border
@@ -537,6 +701,10 @@ k_ms_cell_filter(MsArgs a) {
 // neighbours, and the exact test decides.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float ms_share(float v, const MsArgs& a) { return a.pow2 ? v * a.n_rcp : v / a.n_div; }
+
+// floor(e / d) for 0 <= e < 2^16, 1 <= d < 2^8, as a multiplication: m = ceil(2^24 / d).
+__device__ __forceinline__ unsigned msv_magic(int d) { return ((1u << 24) + (unsigned)d - 1u) / (unsigned)d; }
+__device__ __forceinline__ int msv_div(int e, unsigned m) { return (int)(((unsigned long long)(unsigned)e * m) >> 24); }
 
 __global__ void __launch_bounds__(MSV_NT)
 k_ms_verify(MsArgs a) {
@@ -583,9 +751,10 @@ k_ms_verify(MsArgs a) {
             }
             const int j_lo = pd_up8_ofs(pr_lo);
             const int nj = pd_up8_ofs(pr_lo + ph - 1) + 3 - j_lo + 1;
+            const unsigned m_pw = msv_magic(pw), m_nw = msv_magic(nw);
             // x8 resize, horizontal: source row j_lo + jj (clamped), patch column c
             for (int e = tid; e < nj * pw; e += MSV_NT) {
-                const int jj = e / pw, c = e - jj * pw;
+                const int jj = msv_div(e, m_pw), c = e - jj * pw;
                 const int col = pc_lo + c, x0 = pd_up8_ofs(col);
                 const float4 w = s_up[pd_up8_phase(col)];
                 const float* row = src + (size_t)pd_clampi(j_lo + jj, 0, hs - 1) * ws;
@@ -596,7 +765,7 @@ k_ms_verify(MsArgs a) {
             __syncthreads();
             // x8 resize, vertical: the patch
             for (int e = tid; e < ph * pw; e += MSV_NT) {
-                const int r = e / pw, c = e - r * pw;
+                const int r = msv_div(e, m_pw), c = e - r * pw;
                 const int rabs = pr_lo + r;
                 const float* hcol = hsum + (pd_up8_ofs(rabs) - j_lo) * MSV_P + c;
                 const float4 w = s_up[pd_up8_phase(rabs)];
@@ -605,13 +774,13 @@ k_ms_verify(MsArgs a) {
             __syncthreads();
             if (sc.identity) {
                 for (int e = tid; e < nh * nw; e += MSV_NT) {
-                    const int yo = e / nw, xo = e - yo * nw;
+                    const int yo = msv_div(e, m_nw), xo = e - yo * nw;
                     avg[yo * 28 + xo] = avg[yo * 28 + xo] + (double)ms_share(patch[yo * (MSV_P + 1) + xo], a);
                 }
             } else {
                 // second resize, horizontal: patch row r, window column xo
                 for (int e = tid; e < ph * nw; e += MSV_NT) {
-                    const int r = e / nw, xo = e - r * nw;
+                    const int r = msv_div(e, m_nw), xo = e - r * nw;
                     const int Xa = cmin + xo, x0 = sc.tx.ofs[Xa];
                     const float4 ac = *(const float4*)(sc.tx.coef + 4 * (size_t)Xa);
                     const float* prow = patch + r * (MSV_P + 1) - pc_lo;
@@ -622,7 +791,7 @@ k_ms_verify(MsArgs a) {
                 __syncthreads();
                 // second resize, vertical; float32 share of the average; float64 sum
                 for (int e = tid; e < nh * nw; e += MSV_NT) {
-                    const int yo = e / nw, xo = e - yo * nw;
+                    const int yo = msv_div(e, m_nw), xo = e - yo * nw;
                     const int Ya = rmin + yo, y0 = sc.ty.ofs[Ya];
                     const float4 bc = *(const float4*)(sc.ty.coef + 4 * (size_t)Ya);
                     const float* hc2 = h2 + xo - pr_lo * 28;
@@ -717,6 +886,7 @@ int pd_launch_peaks_filtered_multi(pd_ctx* ctx, double thr) {
         sc.crop_h = ctx->ms_crop_h[m];
         sc.crop_w = ctx->ms_crop_w[m];
         sc.identity = sc.crop_h == H && sc.crop_w == W;
+        sc.nq = ctx->msf_nq[m];
         sc.y.cw = ctx->msf_tab + lay.cw[m][0];
         sc.y.bw = ctx->msf_tab + lay.bw[m][0];
         sc.y.lo = ctx->msf_lo + lay.lo[m][0];
@@ -762,9 +932,13 @@ int pd_launch_peaks_filtered_multi(pd_ctx* ctx, double thr) {
     pd_prof_begin(ctx, PD_STAGE_PLANAR);
     hipLaunchKernelGGL(k_ms_planar, dim3((max_pix + MSP_PIX - 1) / MSP_PIX, B, n), dim3(256), 0, ctx->stream, pa);
     pd_prof_end(ctx);
-    const size_t cells_lds = ((size_t)hc * wc + a.lds_a + a.lds_r) * sizeof(float);
     pd_prof_begin(ctx, PD_STAGE_CELLS);
-    hipLaunchKernelGGL(k_ms_cells, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(256), cells_lds, ctx->stream, a);
+    if (hc <= 64 && wc <= 64)
+        hipLaunchKernelGGL(k_ms_cells64, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(256), ((size_t)a.lds_a + a.lds_r) * sizeof(float),
+                           ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_ms_cells, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(256),
+                           ((size_t)hc * wc + a.lds_a + a.lds_r) * sizeof(float), ctx->stream, a);
     pd_prof_end(ctx);
     // the list lengths are only known on the device: a fixed grid strides over them
     size_t fblocks = (planes * hc * wc / 16 + 3) / 4;
