@@ -292,10 +292,61 @@ k_ms_planar(MsPlanarArgs a) {
 // in LDS, the row sums R[s][cx] = sum_t Bx[cx][t] |src[s][t]| are formed for every source row and
 // cell column, then every cell adds sum_s By[cy][s] R[s][cx] to its bound.
 // ---------------------------------------------------------------------------------
+// One scale of the bound for a thread's cell column: the row sums of its column for every fourth
+// source row, then (behind a barrier) the bounds of its cells.  Free of branches, so that the
+// loads of the row weights of all sixteen cell rows can be in flight at once.
+template <int NQ>
+__device__ __forceinline__ void ms_cells_scale(const MsScale& sc, const float* A, float* R, int hc, int wc, int cx, int wv, bool act,
+                                               float (&U)[16]) {
+    const int hs = sc.hs, ws = sc.ws;
+    const int cxc = min(cx, wc - 1);
+    float bw[4 * NQ];
+    int col[4 * NQ];
+    {
+        const int lo = sc.x.lo[cxc];
+        const float4* b4 = (const float4*)(sc.x.bw + (size_t)cxc * MSF_T);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 w = b4[q];
+            bw[4 * q] = w.x;
+            bw[4 * q + 1] = w.y;
+            bw[4 * q + 2] = w.z;
+            bw[4 * q + 3] = w.w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) col[4 * q + k] = min(lo + 4 * q + k, ws - 1);
+        }
+    }
+    __syncthreads();  // A is staged
+    if (act)
+        for (int s = wv; s < hs; s += 4) {
+            const float* row = A + s * ws;
+            float acc = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4 * NQ; ++p) acc = fmaf(bw[p], row[col[p]], acc);
+            R[s * wc + cx] = acc;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int cy = __builtin_amdgcn_readfirstlane(min(wv + 4 * k, hc - 1));
+        const int lo = sc.y.lo[cy];
+        const float4* by = (const float4*)(sc.y.bw + (size_t)cy * MSF_T);
+        float acc = U[k];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 w = by[q];
+            acc = fmaf(w.x, R[min(lo + 4 * q, hs - 1) * wc + cxc], acc);
+            acc = fmaf(w.y, R[min(lo + 4 * q + 1, hs - 1) * wc + cxc], acc);
+            acc = fmaf(w.z, R[min(lo + 4 * q + 2, hs - 1) * wc + cxc], acc);
+            acc = fmaf(w.w, R[min(lo + 4 * q + 3, hs - 1) * wc + cxc], acc);
+        }
+        U[k] = acc;  // (cell rows beyond the map repeat the last one; they are never listed)
+    }
+}
+
 // Maps of at most 64 x 64 cells: lane = cell column, wavefront = every fourth row.  A thread keeps
-// its column's 16 bound weights and clamped source columns in registers for the row sums, the
-// bounds of its (at most 16) cells in registers as well, and the row weights of the cell row at
-// hand are the same for the whole wavefront (scalar loads).
+// its column's bound weights and clamped source columns in registers for the row sums and the
+// bounds of its (at most 16) cells in registers as well.
 __global__ void __launch_bounds__(256)
 k_ms_cells64(MsArgs a) {
     extern __shared__ __align__(16) float lds[];
@@ -311,8 +362,6 @@ k_ms_cells64(MsArgs a) {
     const bool act = cx < wc;
     float* A = lds;           // [hs][ws] of the scale at hand
     float* R = A + a.lds_a;   // [hs][wc]
-    __shared__ __align__(16) float s_by[64 * MSF_T];  // the row weights of the scale at hand, every cell row
-    __shared__ int s_loy[64];
     float U[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) U[k] = 0.f;
@@ -322,65 +371,31 @@ k_ms_cells64(MsArgs a) {
         const MsScale& sc = a.s[m];
         const int hs = sc.hs, ws = sc.ws, nq = sc.nq;
         const float* src = sc.planar + (size_t)plane * hs * ws;
-        for (int i = tid; i < hs * ws; i += 256) {
-            const float v = fabsf(src[i]);
-            A[i] = v;
-            mx = fmaxf(mx, v);
-        }
-        for (int i = tid; i < hc * (MSF_T / 4); i += 256) ((float4*)s_by)[i] = ((const float4*)sc.y.bw)[i];
-        if (tid < hc) s_loy[tid] = sc.y.lo[tid];
-        float bw[MSF_T];
-        int col[MSF_T];
-        {
-            const int lo = act ? sc.x.lo[cx] : 0;
-            const float4* b4 = (const float4*)(sc.x.bw + (size_t)(act ? cx : 0) * MSF_T);
+        // (eight loads per thread in flight at a time)
+        for (int i0 = 0; i0 < hs * ws; i0 += 256 * 8) {
+            float t[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w = b4[q];
-                bw[4 * q] = w.x;
-                bw[4 * q + 1] = w.y;
-                bw[4 * q + 2] = w.z;
-                bw[4 * q + 3] = w.w;
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 256 * k + tid;
+                t[k] = i < hs * ws ? src[i] : 0.f;
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) col[4 * q + k] = min(lo + 4 * q + k, ws - 1);
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 256 * k + tid;
+                if (i < hs * ws) {
+                    A[i] = fabsf(t[k]);
+                    mx = fmaxf(mx, fabsf(t[k]));
+                }
             }
         }
-        __syncthreads();
-        if (act)
-            for (int s = wv; s < hs; s += 4) {
-                const float* row = A + s * ws;
-                float acc = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < nq) {
-                        acc = fmaf(bw[4 * q], row[col[4 * q]], acc);
-                        acc = fmaf(bw[4 * q + 1], row[col[4 * q + 1]], acc);
-                        acc = fmaf(bw[4 * q + 2], row[col[4 * q + 2]], acc);
-                        acc = fmaf(bw[4 * q + 3], row[col[4 * q + 3]], acc);
-                    }
-                R[s * wc + cx] = acc;
-            }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int cy = __builtin_amdgcn_readfirstlane(wv + 4 * k);
-            if (cy < hc && act) {
-                const int lo = s_loy[cy];
-                const float4* by = (const float4*)(s_by + cy * MSF_T);
-                float acc = U[k];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < nq) {
-                        const float4 w = by[q];
-                        acc = fmaf(w.x, R[min(lo + 4 * q, hs - 1) * wc + cx], acc);
-                        acc = fmaf(w.y, R[min(lo + 4 * q + 1, hs - 1) * wc + cx], acc);
-                        acc = fmaf(w.z, R[min(lo + 4 * q + 2, hs - 1) * wc + cx], acc);
-                        acc = fmaf(w.w, R[min(lo + 4 * q + 3, hs - 1) * wc + cx], acc);
-                    }
-                U[k] = acc;
-            }
-        }
-        __syncthreads();  // the row weights are replaced by the next scale's
+        if (nq <= 2)
+            ms_cells_scale<2>(sc, A, R, hc, wc, cx, wv, act, U);
+        else if (nq == 3)
+            ms_cells_scale<3>(sc, A, R, hc, wc, cx, wv, act, U);
+        else
+            ms_cells_scale<4>(sc, A, R, hc, wc, cx, wv, act, U);
+        // (the next scale's first barrier stands between these reads of R and its next writes; A was
+        // last read before the second barrier)
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
