@@ -118,7 +118,7 @@ def main():
     ap.add_argument('--no-stage-timing', action='store_true',
                     help='experiments: no event pair around the roofline kernel in the timed region')
     ap.add_argument('--contexts', type=int, default=0,
-                    help='decode contexts (HIP streams) per GPU, used round-robin (0: 4, 3 in the round pipeline; 1 for the multi-scale workload, whose kernels fill the chip by themselves)')
+                    help='decode contexts (HIP streams) per GPU, used round-robin (0: 4; 3 in the round pipeline and for the multi-scale workload)')
     ap.add_argument('--depth', type=int, default=0,
                     help='fetch pipeline: contexts per stream, used in turn, so that a stream holds that many '
                          'decodes (0: 2 for maps of at most 4096 pixels, else 1; the round pipeline keeps its own depth)')
@@ -129,7 +129,7 @@ def main():
                          'launcher threads).  Default: fetch, rounds for the stream workload')
     ap.add_argument('--hw-queues', type=int, default=-1,
                     help='GPU_MAX_HW_QUEUES for this process when the environment asks for fewer '
-                         '(0: leave it; -1: 8, left alone for the multi-scale workload)')
+                         '(0: leave it; -1: 8)')
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     if args.steps <= 0:
@@ -146,9 +146,9 @@ def main():
     # round pipeline three next to the stream of its gather / copy (measured: rounds with four
     # contexts 0.77 M images/s on four queues and 0.65 M on eight, with three on eight 1.0 M).
     if args.contexts <= 0:
-        args.contexts = 1 if multiscale else (3 if rounds else 4)
+        args.contexts = 3 if (multiscale or rounds) else 4
     if args.hw_queues < 0:
-        args.hw_queues = 0 if multiscale else 8
+        args.hw_queues = 8
 
     # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default);
     # streams that share a queue run one behind the other.  Every decode context needs a
@@ -199,15 +199,128 @@ def main():
                torch=torch, dist=dist, all_cores=all_cores, token=torch.zeros(1, device='cuda') if use_dist else None)
     out = run_multiscale(env) if multiscale else run_single(env)
     parity_failed = False
+    if rank == 0 and world == 1 and not use_dist and not args.no_extras and not profiled and args.workload == 'b64_368' \
+            and not args.people and os.environ.get('PD_BENCH_NO_OTHERS') != '1':
+        # the default run also times short regions of the other configurations, the headline batch
+        # in the other decode variant and one image through detect()
+        others_failed = other_workloads(env, out)
+        parity_failed = parity_failed or others_failed
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-        parity_failed = out.get('parity_ok') is False
+        parity_failed = parity_failed or out.get('parity_ok') is False
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if parity_failed:
         raise SystemExit('bench: the decode differs from the CPU oracle (parity_ok false)')
+
+
+def other_workloads(env, out):
+    """Short timed regions of the configurations the headline line does not carry (BASELINE
+    configs 3, 4, 5), the headline batch under utils/postprocess.py semantics (mode P: the half of
+    the oracle that is pinned by the reference's own outputs) and a single image through
+    detect() (config 1's shape).  Fills out['other_workloads'], out['mode_p'] and
+    out['detect_single_image']; returns True if any parity check failed."""
+    import copy
+    args = env['args']
+    failed = False
+    legs = {}
+    for name, steps, cpu_images in (('b256_656', 40, 2), ('ms4_b128_368', 40, 4), ('stream_b1024_368', 20, 4)):
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.no_extras, a.cpu_images = name, steps, 3, True, cpu_images
+        a.contexts, a.depth, a.pipeline = 0, 0, ''
+        wl = dict(WORKLOADS[name])
+        wl['scenes'] = 32          # distinct scenes, repeated to the batch (rendering 256 crowded scenes takes a minute of CPU)
+        multiscale = wl['kind'] == 'multiscale'
+        a.pipeline = 'rounds' if wl['per_step'] > 1 else 'fetch'
+        a.contexts = 3 if multiscale or a.pipeline == 'rounds' else 4
+        e = dict(env, args=a, wl=wl, rounds=(a.pipeline == 'rounds') and not multiscale, all_cores=None)
+        try:
+            r = run_multiscale(e) if multiscale else run_single(e)
+        except Exception as exc:            # a leg that fails is reported, it does not take the headline down
+            legs[name] = {'error': repr(exc)}
+            failed = True
+            continue
+        roof = r['roofline']
+        legs[name] = {'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'], 'steps': steps,
+                      'batch_per_step': r['config']['batch_per_gpu'], 'contexts': r['config']['contexts_per_gpu'],
+                      'parity_ok': r.get('parity_ok'), 'parity_checked_images': r.get('parity_checked_images'),
+                      'roofline': {k: roof.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+                                                            'algorithmic_bytes_per_launch', 'wasted_traffic_ratio', 'dominant_kernel')},
+                      'cpu_baseline': r.get('cpu_baseline')}
+        for k, v in roof.items():           # the per-kernel entries (event-timed in the leg's own region)
+            if isinstance(v, dict) and 'avg_launch_ms' in v:
+                legs[name]['roofline'][k] = v
+        if 'kernels' in roof:
+            legs[name]['roofline']['kernels'] = roof['kernels']
+        failed = failed or r.get('parity_ok') is False
+    out['other_workloads'] = legs
+    # the headline batch in mode P
+    a = copy.copy(args)
+    a.mode, a.steps, a.warmup, a.no_extras, a.cpu_images = 'P', 200, 5, True, 6
+    try:
+        r = run_single(dict(env, args=a, all_cores=None))
+        out['mode_p'] = {'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'], 'steps': 200,
+                         'parity_ok': r.get('parity_ok'), 'parity_checked_images': r.get('parity_checked_images'),
+                         'note': 'the headline batch decoded with utils/postprocess.py semantics (the variant whose oracle is '
+                                 'pinned by outputs of the reference itself); PAFs rendered in its (y, x) channel order'}
+        failed = failed or r.get('parity_ok') is False
+    except Exception as exc:
+        out['mode_p'] = {'error': repr(exc)}
+        failed = True
+    try:
+        out['detect_single_image'] = detect_latency(env)
+        failed = failed or out['detect_single_image'].get('parity_ok') is False
+    except Exception as exc:
+        out['detect_single_image'] = {'error': repr(exc)}
+        failed = True
+    return failed
+
+
+def detect_latency(env):
+    """One 368 x 368 image, four test scales, through predict_decode.detect() (predict.py:45-254)
+    with a stand-in network that returns rendered scenes: latency per image of everything but
+    the network, host arrays in and Python structures out, beside the CPU restatement of the
+    same loop."""
+    from poseestimation_amd import predict_decode as pdec, synth
+    from oracle import decode_ref as ref
+    H = W = 368
+    outs = {}
+    for s in SCALES:
+        hm, pf = synth.scene(H, W, 5, 4242, paf_order='xy', scale=s)
+        outs[hm.shape[0]] = (hm[None], pf[None])
+
+    def network(batch):             # (1, h, w, 3) padded image -> the scene's outputs at that size
+        return outs[batch.shape[1] // 8]
+
+    img = np.random.RandomState(3).randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+    pdec.detect(img, network)       # tables, buffers
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        cand, peaks, subset = pdec.detect(img, network)
+    t_detect = (time.perf_counter() - t0) / n
+    pairs = [outs[k] for k in sorted(outs)]
+    pads = [(0, 0)] * len(pairs)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pdec.decode_scales(pairs, pads, (H, W))
+    t_decode = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    want_h, want_p = ref.upsample_average([p[0][0] for p in pairs], [p[1][0] for p in pairs], pads, (H, W))
+    w_cand, w_peaks, w_subset = ref.decode(want_h, want_p, 0.1, 0.05, 'D')
+    t_cpu = time.perf_counter() - t0
+    ok = w_subset.shape == subset.shape and np.array_equal(w_subset[:, :18], subset[:, :18]) \
+        and np.allclose(w_subset[:, 18:], subset[:, 18:], rtol=1e-5, atol=0) and np.array_equal(w_cand[:, :2], cand[:, :2])
+    in_bytes = sum(p[0].nbytes + p[1].nbytes for p in pairs)
+    return {'image': '368x368, 5 people, scales 0.5 / 1 / 1.5 / 2', 'detect_ms': t_detect * 1e3,
+            'decode_scales_ms': t_decode * 1e3, 'cpu_restatement_ms': t_cpu * 1e3, 'host_input_bytes': in_bytes,
+            'persons': int(len(subset)), 'parity_ok': bool(ok),
+            'note': 'detect_ms: image resize + pad of four scales on the device (host arrays in and out), the stand-in '
+                    'network, then decode_scales; decode_scales_ms: predict.py:63-254 alone -- network outputs uploaded '
+                    'from host arrays, one enqueue, results fetched and rebuilt as the reference\'s Python structures; '
+                    'cpu_restatement_ms: oracle/decode_ref.py upsample_average + decode of the same outputs, one thread'}
 
 
 def make_barrier(env):
@@ -257,7 +370,12 @@ def run_single(env):
         people = args.people
         desc += ' (people per image overridden: %d)' % people
     h, w = H // 8, W // 8
-    heat, paf = synth.batch(B, H, W, people, seed0=rank * B, paf_order='xy' if args.mode == 'D' else 'yx')
+    n_scenes = min(B, wl.get('scenes', B))
+    heat, paf = synth.batch(n_scenes, H, W, people, seed0=rank * B, paf_order='xy' if args.mode == 'D' else 'yx')
+    if n_scenes < B:        # short legs: fewer distinct scenes, repeated to the batch
+        reps = -(-B // n_scenes)
+        heat, paf = np.concatenate([heat] * reps)[:B], np.concatenate([paf] * reps)[:B]
+        desc += ' (%d distinct scenes repeated to the batch)' % n_scenes
     # Distinct input buffers, used in turn, so that no step finds its inputs in the caches left
     # by the step before (together they exceed the 256 MiB Infinity Cache at 368^2): buffer k
     # holds the batch rotated by k images, i.e. image b of buffer k is image (b + k) % B.
@@ -642,7 +760,7 @@ def run_multiscale(env):
 
     B, H, W, people = wl['B'], wl['H'], wl['W'], wl['people']
     # 32 distinct scenes per rank, each rendered at the four test scales, repeated to the batch
-    NSCENE = min(32, B)
+    NSCENE = min(32, B, wl.get('scenes', B))
     rng = np.random.RandomState(100003 + rank)
     counts = [int(rng.randint(people[0], people[1] + 1)) for _ in range(NSCENE)]
     heats, pafs = [], []
@@ -683,7 +801,7 @@ def run_multiscale(env):
         else:
             e.ctx.decode_multiscale(hp, pp, sizes, crops, H, W, B, 0.1, 0.05)
 
-    def run(nsteps):
+    def run(nsteps, pool=None):
         if gather is not None:
             n, r, done, last = len(engs), 0, 0, None
             busy = [False, False]
@@ -708,10 +826,11 @@ def run_multiscale(env):
                         last = rows
             # (rank 0) the images of all ranks, in image order
             return None if last is None else sharding.SkeletonGather.results(last)[0]
+        pool = pool or engs
         pending, last = [], None
         for i in range(nsteps):
-            e = engs[i % len(engs)]
-            if len(pending) == len(engs):
+            e = pool[i % len(pool)]
+            if len(pending) == len(pool):
                 last = pending.pop(0).ctx.fetch()
             decode(e)
             pending.append(e)
@@ -746,6 +865,13 @@ def run_multiscale(env):
             stage[k] = (a[0] + v[0], a[1] + v[1])
     dt = max_over_ranks(env, dt)
     prof = {}
+    if rank == 0 and gather is None and len(engs) > 1:
+        # the same event pairs with one context decoding alone: a kernel's own duration (what a
+        # kernel trace reports); with several contexts the kernels of different steps share the chip
+        run(4, pool=engs[:1])
+        engs[0].ctx.profile_read()
+        run(10, pool=engs[:1])
+        prof = engs[0].ctx.profile_read()
 
     out = None
     if rank == 0:
@@ -775,7 +901,7 @@ def run_multiscale(env):
         }
         if traffic:
             roofline['wasted_traffic_ratio'] = traffic / must
-        per_stage = {k: v[0] / v[1] for k, v in stage.items() if v[1]}
+        per_stage = {k: v[0] / v[1] for k, v in (prof or stage).items() if v[1]}
         # per-kernel figures: algorithmic bytes of each kernel of the chain / its event-timed duration
         kbytes = {
             'planar': ('k_ms_planar', B * 4.0 * n_sum * (19 + 18), 'heatmaps of the four scales read (19 channels), planar copies written (18)'),
@@ -796,10 +922,11 @@ def run_multiscale(env):
                     for pk_name, kv in pmc['kernels'].items():
                         if pk_name.split('(')[0].split('<')[0] == kname:
                             kt = kv['hbm_bytes']
-                kern[kname] = {'avg_launch_ms': ms, 'launches': stage[st][1], 'algorithmic_bytes_per_launch': nbytes,
+                kern[kname] = {'avg_launch_ms': ms, 'launches': (prof or stage)[st][1], 'algorithmic_bytes_per_launch': nbytes,
                                'bytes_counted': what, 'achieved': nbytes / (ms * 1e-3) / 1e9,
                                'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': kt,
-                               'measured': 'HIP event pair around the kernel in every step of the timed region'}
+                               'measured': 'HIP event pair around the kernel, one context decoding alone (ten steps behind the timed region)'
+                                           if prof else 'HIP event pair around the kernel in every step of the timed region'}
         roofline['kernels'] = kern
         if per_stage:
             dom = max(per_stage, key=per_stage.get)
@@ -819,7 +946,7 @@ def run_multiscale(env):
             'stage_ms_per_step_timed_region': {k: v[0] / args.steps for k, v in stage.items() if v[1]},
         }
         if prof:
-            out['stage_ms_per_launch_untimed_pass'] = {k: v[0] / v[1] for k, v in prof.items() if v[1]}
+            out['stage_ms_per_launch_one_context'] = {k: v[0] / v[1] for k, v in prof.items() if v[1]}
         out['persons_last_step'] = int(last['person_count'].sum())
         if gather is None:
             out['filter_stats_last_step'] = engs[0].ctx.filter_stats()

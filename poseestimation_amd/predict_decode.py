@@ -3,6 +3,7 @@
 * ``pad_right_down_corner``  predict.py:19-32
 * ``upsample_average``       predict.py:51-72   (x8 bicubic, un-pad, resize, multi-scale average)
 * ``decode``                 predict.py:82-254  -> ``(candidate, all_peaks, subset)``
+* ``decode_scales``          predict.py:63-254 from the network outputs of the scales, no maps stored
 * ``DecodeEngine``           the batched form: many images per call, results packed
 * ``resize_pad``             predict.py:56-57  (image-side cubic resize + padding, on the device)
 * ``detect``                 predict.py:45 signature; the network is the caller's ``predict_func``
@@ -160,13 +161,43 @@ def upsample_average(net_outputs_per_scale, pads, out_hw):
         pafs.append(pf[None] if pf.ndim == 3 else pf)
     pads2 = [(p[2], p[3]) if len(p) == 4 else tuple(p) for p in pads]
     H, W = out_hw
-    eng = DecodeEngine(1, H, W, mode='D', max_peaks_per_part=16, max_pairs_per_image=16, max_persons=16)
-    try:
-        eng.upsample_average(heats, pafs, pads2, (H, W))
-        heat, paf = eng.ctx.read_fullres(1, H, W)
-    finally:
-        eng.close()
+    ctx = _pp._context(H, W, 128, 32768, 128)       # the cached context of this process
+    crops = [(a.shape[1] * STRIDE - p[0], a.shape[2] * STRIDE - p[1]) for a, p in zip(heats, pads2)]
+    ctx.upsample_avg(heats, pafs, crops, H, W, 1)
+    heat, paf = ctx.read_fullres(1, H, W)
     return heat[0], paf[0]
+
+
+def decode_scales(net_outputs_per_scale, pads, out_hw, thre1=THRE1, thre2=THRE2, mode='D'):
+    """predict.py:63-254 for one image from the network outputs of the test scales:
+    ``(candidate, all_peaks, subset)``, the result of ``decode(*upsample_average(..))`` without
+    the averaged maps being stored, read back or uploaded again (the decode evaluates them on
+    the device where it reads them)."""
+    m = _MODES[mode]
+    heats, pafs = [], []
+    for hm, pf in net_outputs_per_scale:
+        hm = np.ascontiguousarray(hm, np.float32)
+        pf = np.ascontiguousarray(pf, np.float32)
+        heats.append(hm[None] if hm.ndim == 3 else hm)
+        pafs.append(pf[None] if pf.ndim == 3 else pf)
+    pads2 = [(p[2], p[3]) if len(p) == 4 else tuple(p) for p in pads]
+    H, W = out_hw
+    sizes = [a.shape[1:3] for a in heats]
+    crops = [(a.shape[1] * STRIDE - p[0], a.shape[2] * STRIDE - p[1]) for a, p in zip(heats, pads2)]
+    pk, pairs = 128, 32768
+    while True:
+        ctx = _pp._context(H, W, pk, pairs, 128)
+        ctx.set_mode(m)
+        ctx.decode_multiscale([a.ctypes.data for a in heats], [a.ctypes.data for a in pafs], sizes, crops, H, W, 1,
+                              thre1, thre2, _ffi.MEM_HOST)
+        try:
+            res = Results(ctx.fetch(), m)
+            break
+        except _ffi.DecodeOverflow:
+            if pk >= 4096:
+                raise
+            pk, pairs = pk * 4, pairs * 16
+    return res.image(0)
 
 
 def decode(heatmap_avg, paf_avg, thre1=THRE1, thre2=THRE2, mode='D'):
@@ -218,7 +249,15 @@ def detect(img, predict_func, draw_result=False, resize=None):
     ``(candidate, all_peaks, subset)``.  The multi-scale loop is predict.py:49-72: the
     image-side cubic resize and padding (predict.py:56-57) run on the device
     (``resize_pad``) unless ``resize(img, scale)`` is given, in which case its result is
-    padded on the host; the network call is the caller's ``predict_func``."""
+    padded on the host; the network call is the caller's ``predict_func``.  Everything behind
+    the network calls (predict.py:63-254) is one enqueue on the process's cached context
+    (``decode_scales``): no averaged map is stored, read back or uploaded.
+
+    Parity of the image-side resize is unpinned: ``cv2.resize`` on 8-bit images is a
+    fixed-point cubic whose last bit depends on the OpenCV build, ``resize_pad`` evaluates the
+    cubic in float32 and rounds half to even, and the reference holds no fixture for either.
+    Callers that have OpenCV and want its very bytes pass ``resize=lambda im, s: cv2.resize(im,
+    (0, 0), fx=s, fy=s, interpolation=cv2.INTER_CUBIC)``."""
     h, w = img.shape[:2]
     outs, pads = [], []
     for x in SCALE_SEARCH:
@@ -230,8 +269,7 @@ def detect(img, predict_func, draw_result=False, resize=None):
         heatmap, paf = predict_func(np.expand_dims(padded, axis=0))   # predict.py:59-61
         outs.append((heatmap, paf))
         pads.append(pad)
-    heat_avg, paf_avg = upsample_average(outs, pads, (h, w))
-    return decode(heat_avg, paf_avg, THRE1, THRE2, mode='D')
+    return decode_scales(outs, pads, (h, w), THRE1, THRE2, mode='D')
 
 
 def render_lists(candidate, all_peaks, subset):
