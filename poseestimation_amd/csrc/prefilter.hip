@@ -967,8 +967,283 @@ k_cells_filter(CellsFilterArgs args) {
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Small maps, by tiles: one workgroup owns a tile of 8 x 8 cells of one image for all 18 parts.
+// It reads the 16 x 16 network pixels its cells draw on (4 either side, clamped to the map) once,
+// as whole (h, w, 19) pixels -- every byte of every cache line it touches is used -- and
+// transposes them into per-part planes in LDS.  Tolerance: the float32 evaluation of an output of
+// the tile, and the reference's own rounding of it, involve the sources of the tile only, so the
+// bound eps = 2^-17 * M holds with M = max |src| of the part over the staged tile (instead of
+// over the whole plane).  Bounds, list and filter then run as in k_cells_filter, on LDS alone;
+// no planar copy is written: the verification reads the network output itself.
+// ---------------------------------------------------------------------------------
+#define TF_TC 8                             // cells per tile side
+#define TF_SRC (TF_TC + 8)                  // staged pixels per tile side
+#define TF_PSTR (TF_SRC + 1)                // row stride of a staged plane, in floats
+#define TF_PLANE (TF_SRC * TF_PSTR + 1)     // plane stride: odd, so that the 19 channels of a pixel fall in distinct banks
+#define TF_CELLS (TF_TC * TF_TC * PD_N_PARTS)
+
+struct TileFilterShared {
+    float P[PD_N_PARTS * TF_PLANE];
+    union {
+        float rs[PD_N_PARTS * (TF_TC + 6) * TF_TC];   // row sums of the bound: part, source row, cell column
+        struct {
+            float tile[KF_CELLS_PER_BLOCK][9][10];
+            __attribute__((aligned(16))) float wts[KF_CELLS_PER_BLOCK][72];
+        } f;
+    } u;
+    unsigned short list[TF_CELLS];  // part << 6 | cell row << 3 | cell column (within the tile); interior-weight cells from the front
+    int2 cand[KF_LCAND_PLANE];
+    unsigned int absmax[PD_N_PARTS];
+    float thr_lo[PD_N_PARTS], e2[PD_N_PARTS];
+    int n_reg, n_edge, n_cand, base;
+};
+
+template <bool REG>
+__device__ __forceinline__ void filter_cells_tile(const CellFilterArgs& a, TileFilterShared& sh, const unsigned short* list, int n,
+                                                  int list_step, int b, int cy0, int cx0, int lane) {
+    const int wv = threadIdx.x >> 6;
+    const int cs = lane / 10, r = lane - cs * 10;
+    const bool lane_ok = cs < KF_CELLS_PER_WAVE;
+    const int slot = wv * KF_CELLS_PER_WAVE + (lane_ok ? cs : 0);
+    const int H = a.H, W = a.W;
+    float* wl = &sh.u.f.wts[slot][0];
+    for (int base = wv * KF_CELLS_PER_WAVE; base < n; base += KF_CELLS_PER_BLOCK) {
+        const int ci = base + cs;
+        const bool act = lane_ok && ci < n;
+        int cy = 0, cx = 0, part = 0;
+        float thr_lo = 0.f, e2 = 0.f;
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = 0.f;
+        if (act) {
+            const int e = list[ci * list_step];
+            part = e >> 6;
+            const int cyl = (e >> 3) & 7, cxl = e & 7;
+            cy = cy0 + cyl;
+            cx = cx0 + cxl;
+            thr_lo = sh.thr_lo[part];
+            e2 = sh.e2[part];
+            if (r < 9) {
+                // rows cy-4 .. cy+4, columns cx-4 .. cx+4 of the map (clamped when staged) = rows cyl .. cyl+8 of the tile
+                const float* p = sh.P + part * TF_PLANE + (cyl + r) * TF_PSTR + cxl;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) v[k] = p[k];
+            }
+        }
+        if (!REG) {
+            if (act && r < 9) {
+                const float4* kq = (const float4*)(a.cx + (size_t)cx * 72);
+                ((float4*)wl)[2 * r] = kq[2 * r];
+                ((float4*)wl)[2 * r + 1] = kq[2 * r + 1];
+            }
+            pd_wave_sync();
+        }
+        // x pass: lane r < 9 owns source row y-4+r and forms the ten column sums
+        if (act && r < 9) {
+            float* out = &sh.u.f.tile[slot][r][0];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const ConstF* kp = fresh_pointer(c_kf_interior);
+#pragma unroll
+                for (int i = 5 * half; i < 5 * half + 5; ++i) {
+                    const int p0 = i == 0 ? 0 : (i == 9 ? 2 : 1);
+                    if (!REG) asm volatile("" ::: "memory");  // keeps the weight reads of later sums out of registers
+                    float s = (REG ? kp[7 * i] : wl[7 * i]) * v[p0];
+#pragma unroll
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * i + p] : wl[7 * i + p], v[p0 + p], s);
+                    out[i] = s;
+                }
+            }
+        }
+        pd_wave_sync();  // the tile and the weights are private to this wavefront
+        if (!REG) {
+            if (act && r < 9) {
+                const float4* kq = (const float4*)(a.cy + (size_t)cy * 72);
+                ((float4*)wl)[2 * r] = kq[2 * r];
+                ((float4*)wl)[2 * r + 1] = kq[2 * r + 1];
+            }
+            pd_wave_sync();
+        }
+        // y pass: lane r owns output column 8x-1+r and forms its ten row sums
+        float S[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) S[j] = 0.f;
+        if (act) {
+            float t[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) t[q] = sh.u.f.tile[slot][q][r];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const ConstF* kp = fresh_pointer(c_kf_interior);
+#pragma unroll
+                for (int j = 5 * half; j < 5 * half + 5; ++j) {
+                    const int p0 = j == 0 ? 0 : (j == 9 ? 2 : 1);
+                    if (!REG) asm volatile("" ::: "memory");
+                    float s = (REG ? kp[7 * j] : wl[7 * j]) * t[p0];
+#pragma unroll
+                    for (int p = 1; p < 7; ++p) s = fmaf(REG ? kp[7 * j + p] : wl[7 * j + p], t[p0 + p], s);
+                    S[j] = s;
+                }
+            }
+        }
+        pd_wave_sync();
+        // tolerant NMS of the cell's own 8 x 8 pixels (rows j = 1..8 of lanes r = 1..8);
+        // sums of outputs outside the map are zero, like the reference's zero border
+        const int X = 8 * cx - 1 + r;
+        const bool own = act && r >= 1 && r <= 8 && X < W;
+        unsigned hits = 0;
+#pragma unroll
+        for (int j = 1; j <= 8; ++j) {
+            const float c = S[j];
+            const float ce = c + e2;
+            const float m4 = pd_max_lane_neighbours(c, S[j - 1], S[j + 1]);
+            hits |= (c > thr_lo && ce >= m4) ? (1u << j) : 0u;
+        }
+        if (!own) hits = 0;
+        if (hits) {  // rare
+            const int plane = b * PD_N_PARTS + part;
+#pragma unroll
+            for (int j = 1; j <= 8; ++j) {
+                const int Y = 8 * cy - 1 + j;
+                if (((hits >> j) & 1u) && Y < H) {
+                    atomicAdd(a.cand_count + plane, 1);
+                    const int pos = atomicAdd(&sh.n_cand, 1);
+                    if (pos < KF_LCAND_PLANE)
+                        sh.cand[pos] = make_int2(plane, (Y << 16) | X);
+                    else
+                        atomicOr(a.cand_count + plane, KF_OVERFLOW);  // no room: leave the plane to the exact kernel
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_tile_filter(CellsFilterArgs args, int tiles_x, int tiles_per_image, int n_tiles) {
+    __shared__ TileFilterShared sh;
+    const CellArgs& a = args.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the tiles of an image on one XCD (workgroup i runs on XCD i % 8): neighbouring tiles share halo pixels
+    const int per_xcd = gridDim.x / 8;
+    const int t = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (t >= n_tiles) return;
+    const int b = t / tiles_per_image, ti = t - b * tiles_per_image;
+    const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
+    const int h = a.h, w = a.w, hc = a.hc, wc = a.wc;
+    const int cy0 = ty * TF_TC, cx0 = tx * TF_TC;       // first cell of the tile = its first own network pixel
+    if (tid < PD_N_PARTS) sh.absmax[tid] = 0u;
+    if (tid == 0) {
+        sh.n_reg = 0;
+        sh.n_edge = 0;
+        sh.n_cand = 0;
+    }
+    // ---- the tile's pixels, all 19 channels of each as they lie in memory, into per-part planes
+    {
+        const float* img = a.nhwc + (size_t)b * h * w * PD_CH_HEAT;
+        constexpr int ROWF = TF_SRC * PD_CH_HEAT;          // floats of one staged row
+        constexpr int NF = TF_SRC * ROWF;
+        constexpr int PER = (NF + 255) / 256;
+        float v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + 256 * k;
+            const int r = e / ROWF, rem = e - r * ROWF, c = rem / PD_CH_HEAT, ch = rem - c * PD_CH_HEAT;
+            const int sy = pd_clampi(cy0 - 4 + r, 0, h - 1), sx = pd_clampi(cx0 - 4 + c, 0, w - 1);
+            v[k] = e < NF ? img[((size_t)sy * w + sx) * PD_CH_HEAT + ch] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + 256 * k;
+            const int r = e / ROWF, rem = e - r * ROWF, c = rem / PD_CH_HEAT, ch = rem - c * PD_CH_HEAT;
+            if (e < NF && ch < PD_N_PARTS) sh.P[ch * TF_PLANE + r * TF_PSTR + c] = v[k];
+        }
+    }
+    __syncthreads();
+    // ---- max |v| of every part over the tile: (thr_lo, e2) of its candidate test
+    if (tid < PD_N_PARTS * 14) {
+        const int part = tid / 14, sub = tid - part * 14;
+        const float* pl = sh.P + part * TF_PLANE;
+        float m = 0.f;
+        for (int i = sub; i < TF_SRC * TF_SRC; i += 14) m = fmaxf(m, fabsf(pl[(i >> 4) * TF_PSTR + (i & 15)]));
+        atomicMax(&sh.absmax[part], __float_as_uint(m));
+    }
+    // ---- row sums of the bound: part, source row cy0-3+q (q < 14), cell column (a thread's cell
+    // column is the same in every round: 256 is a multiple of 8)
+    {
+        const int cxl = tid & 7;
+        const float* kxp = a.bx + 8 * min(cx0 + cxl, wc - 1);
+        float kx[7];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) kx[p] = kxp[p];
+        for (int e = tid; e < PD_N_PARTS * 14 * TF_TC; e += 256) {
+            const int part = e / (14 * TF_TC), rem = e - part * (14 * TF_TC), q = rem >> 3;
+            const float* row = sh.P + part * TF_PLANE + (q + 1) * TF_PSTR + cxl + 1;   // columns cx-3 .. cx+3
+            float s = kx[0] * fabsf(row[0]);
+#pragma unroll
+            for (int p = 1; p < 7; ++p) s = fmaf(kx[p], fabsf(row[p]), s);
+            sh.u.rs[e] = s;
+        }
+    }
+    __syncthreads();
+    if (tid < PD_N_PARTS) {
+        float tl, ee;
+        filter_slack(a.thr, __uint_as_float(sh.absmax[tid]), &tl, &ee);
+        sh.thr_lo[tid] = tl;
+        sh.e2[tid] = ee;
+    }
+    __syncthreads();
+    // ---- the bound of every cell; active cells to the list (a thread's cell is the same in every
+    // round, only the part changes)
+    {
+        const int cyl = (tid >> 3) & 7, cxl = tid & 7;
+        const int cy = cy0 + cyl, cx = cx0 + cxl;
+        if (cy < hc && cx < wc) {
+            const float4 ka = *(const float4*)(a.by + 8 * cy), kb = *(const float4*)(a.by + 8 * cy + 4);
+            const bool reg = (a.regy[cy] & a.regx[cx]) != 0;
+            for (int e = tid; e < TF_CELLS; e += 256) {
+                const int part = e >> 6;
+                const float* col = sh.u.rs + (part * 14 + cyl) * TF_TC + cxl;       // rows cy-3 .. cy+3
+                float u = ka.x * col[0];
+                u = fmaf(ka.y, col[TF_TC], u);
+                u = fmaf(ka.z, col[2 * TF_TC], u);
+                u = fmaf(ka.w, col[3 * TF_TC], u);
+                u = fmaf(kb.x, col[4 * TF_TC], u);
+                u = fmaf(kb.y, col[5 * TF_TC], u);
+                u = fmaf(kb.z, col[6 * TF_TC], u);
+                if (u * 1.00001f >= sh.thr_lo[part]) {  // the factor covers the rounding of the chains on both sides
+                    if (reg)
+                        sh.list[atomicAdd(&sh.n_reg, 1)] = (unsigned short)e;
+                    else
+                        sh.list[TF_CELLS - 1 - atomicAdd(&sh.n_edge, 1)] = (unsigned short)e;
+                }
+            }
+        }
+    }
+    __syncthreads();   // (the row sums are dead: the filter's staging areas take their place)
+    const int n_reg = sh.n_reg, n_edge = sh.n_edge;
+    filter_cells_tile<true>(args.f, sh, sh.list, n_reg, 1, b, cy0, cx0, lane);
+    filter_cells_tile<false>(args.f, sh, sh.list + TF_CELLS - 1, n_edge, -1, b, cy0, cx0, lane);
+    __syncthreads();
+    const int seg = t % KF_NSEG;
+    if (tid == 64 && n_reg) atomicAdd(a.n_reg + seg, n_reg);  // the list lengths, for the statistics only
+    if (tid == 128 && n_edge) atomicAdd(a.n_edge + seg, n_edge);
+    const int nc = min(sh.n_cand, KF_LCAND_PLANE);
+    if (nc == 0) return;
+    if (tid == 0) sh.base = atomicAdd(args.f.cand_n + seg, nc);
+    __syncthreads();
+    for (int i = tid; i < nc; i += 256) {
+        const int idx = sh.base + i;
+        if (idx < args.f.cand_seg_cap)
+            args.f.cand[(size_t)seg * args.f.cand_seg_cap + idx] = sh.cand[i];
+        else
+            atomicOr(args.f.cand_count + sh.cand[i].x, KF_OVERFLOW);
+    }
+}
+
 struct VerifyArgs {
-    const float* lo;  // planar copy (B, 19, h, w)
+    const float* lo;  // planar copy (B, 19, h, w), or the network output (B, h, w, 19) itself with px = 19
+    int px;           // floats between horizontally adjacent pixels of a part: 1 (planar) or 19
     const double* full;  // or: full-resolution planes (B, Cfull, H, W)
     int Cfull;
     int h, w, H, W;
@@ -1043,19 +1318,20 @@ k_verify(VerifyArgs a) {
         }
         if (!FULL && active && l < 27) {
             const int b = plane / PD_N_PARTS, part = plane - b * PD_N_PARTS;
-            const float* img = a.lo + ((size_t)b * PD_CH_HEAT + part) * h * w;
+            const int px = a.px;
+            const float* img = px == 1 ? a.lo + ((size_t)b * PD_CH_HEAT + part) * h * w : a.lo + (size_t)b * h * w * PD_CH_HEAT + part;
             // the reflected rows Y-13 .. Y+13 all lie in [max(Y-13, 0), min(Y+13, H-1)]
             const int rmin = max(Y - 13, 0);
             const int ymin = pd_up8_ofs(rmin);
             const int col = pd_reflect(X + l - 13, W);
             const int x0 = pd_up8_ofs(col);
             const float4 ac = s_up[pd_up8_phase(col)];
-            const int xi0 = pd_clampi(x0, 0, w - 1), xi1 = pd_clampi(x0 + 1, 0, w - 1),
-                      xi2 = pd_clampi(x0 + 2, 0, w - 1), xi3 = pd_clampi(x0 + 3, 0, w - 1);
+            const int xi0 = pd_clampi(x0, 0, w - 1) * px, xi1 = pd_clampi(x0 + 1, 0, w - 1) * px,
+                      xi2 = pd_clampi(x0 + 2, 0, w - 1) * px, xi3 = pd_clampi(x0 + 3, 0, w - 1) * px;
             float4 sv[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float* row = img + (size_t)pd_clampi(ymin + q, 0, h - 1) * w;
+                const float* row = img + (size_t)pd_clampi(ymin + q, 0, h - 1) * w * px;
                 sv[q] = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
             }
 #pragma unroll
@@ -1228,6 +1504,31 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         const char* v = getenv("PD_SPLIT_CELLS");
         return v && *v && *v != '0';
     }();  // comparison runs: the two launches also for small maps
+    // PD_TILE_FILTER=1 (comparison runs): small maps by tiles of 8 x 8 cells for all 18 parts -- every
+    // pixel of the network output read once, as a whole, no planar copy, the verification reading
+    // the network output itself.  Measured at batch 64, 368^2: 52 us per launch against 40 us for the
+    // per-plane form below (24 us of it before the filter phase against 21; the filter phase 28 us
+    // against 18: a tile under a person holds up to several hundred active cells of its 18 parts,
+    // an empty one none, where every plane holds one blob per person), 1.25 against 1.29 M images/s.
+    // The strided reads of the per-plane form cost L2-to-L1 traffic, not time.
+    static const bool plane_form = [] {
+        const char* v = getenv("PD_TILE_FILTER");
+        return !(v && *v && *v != '0');
+    }();
+    bool nhwc_verify = false;
+    if (small_map && gather && !split_cells && !plane_form && hc <= h && wc <= w && hc < 128 && wc < 128) {
+        CellsFilterArgs cf;
+        cf.c = c;
+        cf.f = f;
+        const int tiles_x = (wc + TF_TC - 1) / TF_TC, tiles_y = (hc + TF_TC - 1) / TF_TC;
+        const int n_tiles = tiles_x * tiles_y * B;
+        pd_prof_begin(ctx, PD_STAGE_FILTER);
+        hipLaunchKernelGGL(k_tile_filter, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, ctx->stream, cf, tiles_x,
+                           tiles_x * tiles_y, n_tiles);
+        pd_prof_end(ctx);
+        PD_HIP(ctx, hipGetLastError());
+        nhwc_verify = true;
+    } else {
     const size_t fused_lds = sizeof(float) * (size_t)h * w + sizeof(int) * (size_t)hc * wc;
     if (small_map && !split_cells && 256 / wc >= 1 && (hc + 256 / wc - 1) / (256 / wc) <= 32 && hc <= h && wc <= w && hc < 128 && wc < 128 &&
         fused_lds <= 40 * 1024) {
@@ -1271,11 +1572,13 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     pd_prof_end(ctx);
     PD_HIP(ctx, hipGetLastError());
     }
+    }
 
     VerifyArgs v;
     v.full = nullptr;
     v.Cfull = 0;
-    v.lo = ctx->heat_planar;
+    v.lo = nhwc_verify ? ctx->lo_heat : ctx->heat_planar;
+    v.px = nhwc_verify ? PD_CH_HEAT : 1;
     v.h = h;
     v.w = w;
     v.H = H;
@@ -1536,6 +1839,7 @@ int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr) {
 
     VerifyArgs v;
     v.lo = nullptr;
+    v.px = 1;
     v.full = ctx->full_heat;
     v.Cfull = PD_CH_HEAT;
     v.h = v.w = 0;
