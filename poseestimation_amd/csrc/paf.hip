@@ -424,7 +424,12 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
     // sample would come from memory as a line of its own, and the pair-planar copy pays
     a.pairs = nullptr;
     const size_t paf_bytes = sizeof(float) * (size_t)ctx->B * ctx->h * ctx->w * PD_CH_PAF;
-    if (ctx->src_kind == PD_SRC_LOWRES && paf_bytes > ((size_t)64 << 20)) {
+    static const int force_copy = [] {   // comparison runs: PD_PAF_PAIRS=0 never makes the copy, 1 always
+        const char* v = getenv("PD_PAF_PAIRS");
+        return v && *v ? atoi(v) : -1;
+    }();
+    const bool want_copy = force_copy >= 0 ? force_copy != 0 : paf_bytes > ((size_t)64 << 20);
+    if (ctx->src_kind == PD_SRC_LOWRES && want_copy) {
         if (ctx->paf_pairs_cap < paf_bytes) {
             PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
             ctx->gen++;
