@@ -218,3 +218,97 @@ def test_gather_through_the_c_abi_one_rank():
             comm.gather([e.ctx for e in engs], root=0, capacity=64)
     for e in engs:
         e.close()
+
+
+_GATHER_WORLD_SCRIPT = r'''
+import sys, threading
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from poseestimation_amd import _ffi, synth
+from poseestimation_amd.predict_decode import DecodeEngine
+
+WORLD, NCTX, ROOT, H, W, B = 3, 2, 1, 184, 184, 3
+uid = _ffi.Comm.unique_id()
+comms = [_ffi.Comm(uid, WORLD, r, 0) for r in range(WORLD)]
+engs, bufs, want = {}, {}, {}
+plain = DecodeEngine(B, H, W, mode='D')
+for r in range(WORLD):
+    for i in range(NCTX):
+        heat, paf = synth.batch(B, H, W, (1, 4), seed0=1000 + 10 * r + i, paf_order='xy')
+        want[r, i] = plain.decode_batch(heat, paf).packed
+        e = DecodeEngine(B, H, W, mode='D')
+        buf = torch.zeros(1 << 16, dtype=torch.uint8, device='cuda')
+        e.ctx.set_skeleton_buffer(buf.data_ptr(), buf.numel())
+        e.enqueue(heat, paf)
+        engs[r, i], bufs[r, i] = e, buf
+
+
+def gather_all(capacity=1 << 20, ctxs=None):
+    out, err = [None] * WORLD, [None] * WORLD
+
+    def run(r):
+        try:
+            out[r] = comms[r].gather(ctxs[r] if ctxs else [engs[r, i].ctx for i in range(NCTX)], root=ROOT, capacity=capacity)
+        except Exception as exc:
+            err[r] = exc
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(WORLD)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+        assert not t.is_alive(), 'a rank is stuck in pd_gather'
+    return out, err
+
+
+# 1. three ranks, two contexts each, a root that is not rank 0: rank-major, then context order
+out, err = gather_all()
+assert err == [None] * WORLD, err
+assert out[0] is None and out[2] is None and len(out[ROOT]) == WORLD * NCTX
+for r in range(WORLD):
+    for i in range(NCTX):
+        got = _ffi.unpack_results(out[ROOT][r * NCTX + i])
+        for key in ('part_count', 'person_count', 'status', 'peaks', 'persons'):
+            assert np.array_equal(got[key], want[r, i][key]), (r, i, key)
+        assert len(got['conns']) == 0
+print('CASE1 ok')
+# 2. a host array on the root that is too small: reported there, after the exchange; nobody hangs
+out, err = gather_all(capacity=256)
+assert isinstance(err[ROOT], _ffi.DecodeOverflow) and err[0] is None and err[2] is None, err
+print('CASE2 ok')
+# 3. a skeleton buffer that no decode has written (rank 2): every rank gives up together
+fresh = DecodeEngine(B, H, W, mode='D')
+fbuf = torch.zeros(1 << 16, dtype=torch.uint8, device='cuda')
+fresh.ctx.set_skeleton_buffer(fbuf.data_ptr(), fbuf.numel())
+ctxs = {r: [engs[r, i].ctx for i in range(NCTX)] for r in range(WORLD)}
+ctxs[2] = [engs[2, 0].ctx, fresh.ctx]
+out, err = gather_all(ctxs=ctxs)
+assert all(isinstance(e, RuntimeError) for e in err), err
+assert 'does not hold the results' in str(err[2]) and 'holds no decode results' in str(err[0]), err
+print('CASE3 ok')
+# 4. the exchange still works afterwards
+out, err = gather_all()
+assert err == [None] * WORLD and len(out[ROOT]) == WORLD * NCTX
+print('CASE4 ok')
+'''
+
+
+def test_gather_protocol_with_three_ranks_over_a_fake_transport():
+    """pd_gather with a world of three ranks inside one process (host threads, one GPU): RCCL is
+    replaced by tests/fake_rccl (the entry points pd_gather uses, on device-to-device copies), so
+    that the root's receives from other ranks, the rank-major order, a root other than rank 0
+    and the error paths that must not leave a rank waiting all run.  A child process, because the
+    library picks its RCCL once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = os.path.join(root, 'tests', 'fake_rccl', 'libfakerccl.so')
+    if not os.path.exists(fake):
+        pytest.skip('tests/fake_rccl/libfakerccl.so is not built (python -c "import __graft_entry__ as g; g.build()")')
+    env = dict(os.environ, PD_RCCL_LIBRARY=fake)
+    p = subprocess.run([sys.executable, '-c', _GATHER_WORLD_SCRIPT % root], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=200)
+    assert p.returncode == 0, p.stdout[-3000:]
+    for case in ('CASE1 ok', 'CASE2 ok', 'CASE3 ok', 'CASE4 ok'):
+        assert case in p.stdout, p.stdout[-3000:]
