@@ -442,6 +442,11 @@ int pd_launch_pairs(pd_ctx* ctx, double thre2) {
         a.pairs = ctx->paf_pairs;
     }
     if (a.src.kind == PD_SRC_MULTI) {
+        // (workgroups per image, measured at batch 128, 1-8 people: 8 -> 0.205 ms per launch, 16 -> 0.163,
+        // 32 -> 0.149, 64 -> 0.148, 128 -> 0.154: a sample is four dependent rounds of loads, so many
+        // short wavefronts beat few long ones; PD_MS_PAIR_BLOCKS sets it for comparison runs)
+        static const int ms_per_image = getenv("PD_MS_PAIR_BLOCKS") ? atoi(getenv("PD_MS_PAIR_BLOCKS")) : 0;
+        if (ms_per_image >= 8 && ms_per_image % 8 == 0 && ms_per_image <= 256) a.per_image = per_image = ms_per_image;
         const MultiSource ms = pd_multi_source(ctx);
         pd_prof_begin(ctx, PD_STAGE_PAIRS);
         if (ctx->pairs_pre)
