@@ -51,6 +51,9 @@ MS_GEOMETRIES = [  # (H, W, batch, scales)
     (200, 312, 12, (1.0, 2.0)),
     (368, 368, 16, (0.5, 1.0, 1.5)),
     (120, 152, 16, (1.0, 1.5, 2.0)),
+    (361, 275, 12, (0.5, 1.0, 1.5, 2.0)),   # no multiple of 8: pads in every scale
+    (200, 560, 8, (0.5, 1.0, 1.5)),         # more than 64 cell columns: the general form of the bound kernel
+    (480, 640, 4, (0.38, 0.77, 1.15, 1.53)),  # a COCO-sized image at predict.py:49's scales: beyond the sparse stage's staging areas
 ]
 
 
