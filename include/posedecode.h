@@ -390,6 +390,17 @@ const char* pd_comm_last_error(pd_comm* comm);
 int pd_gather(pd_comm* comm, pd_ctx* const* ctxs, int n_ctx, int root, void* recv_host,
               uint64_t recv_capacity, uint64_t* sizes, uint64_t* total_bytes);
 
+/* ---- test hook (host only, touches no GPU) ----
+ * The linear operator the sparse multi-scale peak stage evaluates for one axis of one scale --
+ * scipy's Gaussian (sigma 3, reflect) after the second cubic resize (crop -> L outputs, predict.py:65)
+ * after the x8 resize (l sources, predict.py:63), times `factor` -- as a dense matrix K_out[L][l]
+ * (float64) and in the cell form the kernels read: cw_out[cells][10][16] = weight of source
+ * lo_out[c] + p in output 8c - 1 + j, bw_out[cells][16] = largest magnitude over the cell's own
+ * outputs j = 1..8, cells = (L + 7) / 8.  Any output may be NULL.  Returns the widest window of a
+ * cell, -1 when one exceeds 16 sources, -2 for bad arguments.  No counterpart in the reference. */
+int pd_test_ms_axis(int l, int crop, int L, int identity, double factor, double* K_out, float* cw_out,
+                    float* bw_out, int32_t* lo_out);
+
 #ifdef __cplusplus
 }
 #endif

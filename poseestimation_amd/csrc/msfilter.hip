@@ -169,6 +169,26 @@ static int max_patch_extent(int crop, int L) {
     return worst;
 }
 
+// Test hook (host only, no GPU): the composite operator of one axis of one scale and its cell form,
+// as build_ms_tables makes them.  K_out [L][l] float64; cw_out [cells][10][16], bw_out [cells][16],
+// lo_out [cells] with cells = (L + 7) / 8; any output may be NULL.  Returns the widest window, or
+// -1 when a window exceeds 16 sources (the geometry the sparse stage does not take).
+extern "C" int pd_test_ms_axis(int l, int crop, int L, int identity, double factor, double* K_out, float* cw_out, float* bw_out,
+                               int32_t* lo_out) {
+    if (l < 1 || crop < 1 || L < 1 || crop > 8 * l) return -2;
+    std::vector<double> K;
+    axis_composite(l, crop, L, identity != 0, factor, K);
+    if (K_out) memcpy(K_out, K.data(), K.size() * sizeof(double));
+    std::vector<float> cw, bw;
+    std::vector<int32_t> lo;
+    int widest = 0;
+    if (!axis_cells(L, l, K, cw, bw, lo, &widest)) return -1;
+    if (cw_out) memcpy(cw_out, cw.data(), cw.size() * sizeof(float));
+    if (bw_out) memcpy(bw_out, bw.data(), bw.size() * sizeof(float));
+    if (lo_out) memcpy(lo_out, lo.data(), lo.size() * sizeof(int32_t));
+    return widest;
+}
+
 // Table offsets (floats / ints) of scale m, axis ax (0 = y, 1 = x).
 struct MsLayout {
     size_t cw[PD_MAX_SCALES][2], bw[PD_MAX_SCALES][2], lo[PD_MAX_SCALES][2], n_float, n_int;
@@ -217,7 +237,8 @@ static int build_ms_tables(pd_ctx* ctx) {
         lds_a = std::max(lds_a, (size_t)ctx->ms_hs[m] * ctx->ms_ws[m]);
         lds_r = std::max(lds_r, (size_t)ctx->ms_hs[m] * wc);
     }
-    if ((lds_a + lds_r + (size_t)hc * wc) * sizeof(float) > 63 * 1024) return PD_E_STATE;
+    // (beyond 64 KB a kernel's dynamic LDS has to be asked for: see the launch; a CU has 160 KB)
+    if ((lds_a + lds_r + (size_t)hc * wc) * sizeof(float) > 150 * 1024) return PD_E_STATE;
     const MsLayout lay = ms_layout(n, hc, wc);
     std::vector<float> tab(lay.n_float);
     std::vector<int32_t> los(lay.n_int);
@@ -947,6 +968,19 @@ int pd_launch_peaks_filtered_multi(pd_ctx* ctx, double thr) {
     pd_prof_begin(ctx, PD_STAGE_PLANAR);
     hipLaunchKernelGGL(k_ms_planar, dim3((max_pix + MSP_PIX - 1) / MSP_PIX, B, n), dim3(256), 0, ctx->stream, pa);
     pd_prof_end(ctx);
+    {
+        // workgroups whose staging areas exceed 64 KB (maps of COCO size): the limit is raised once per kernel
+        const size_t need = hc <= 64 && wc <= 64 ? ((size_t)a.lds_a + a.lds_r) * sizeof(float)
+                                                 : ((size_t)hc * wc + a.lds_a + a.lds_r) * sizeof(float);
+        static size_t allowed[2][64];  // per kernel and device; 0 = the default of 64 KB
+        const int dev = ctx->cfg.device_id >= 0 && ctx->cfg.device_id < 64 ? ctx->cfg.device_id : 0;
+        size_t& have = allowed[hc <= 64 && wc <= 64 ? 0 : 1][dev];
+        if (need > 64 * 1024 && need > have) {
+            const void* fn = hc <= 64 && wc <= 64 ? reinterpret_cast<const void*>(k_ms_cells64) : reinterpret_cast<const void*>(k_ms_cells);
+            PD_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            have = 150 * 1024;
+        }
+    }
     pd_prof_begin(ctx, PD_STAGE_CELLS);
     if (hc <= 64 && wc <= 64)
         hipLaunchKernelGGL(k_ms_cells64, dim3((unsigned)((planes + 7) / 8 * 8)), dim3(256), ((size_t)a.lds_a + a.lds_r) * sizeof(float),

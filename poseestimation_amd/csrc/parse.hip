@@ -626,6 +626,23 @@ struct ParsePackArgs {
 };
 
 static_assert(sizeof(pd_conn) == 24, "k_parse_pack copies a connection as three 8-byte words");
+
+// Measurement build only (-DPP_STAMPS, tools/parse_pack_split.py): where a workgroup's time goes.
+// Per workgroup, in units of the 100 MHz wall clock: start, assembly wavefront done, each copy
+// wavefront done, past the barrier, ticket drawn, (last workgroup) person rows placed.
+#ifdef PP_STAMPS
+__device__ long long g_pp_stamps[4096 * 8];
+#define PP_STAMP(slot, cond)                                               \
+    do {                                                                   \
+        if ((cond) && blockIdx.x < 4096) g_pp_stamps[blockIdx.x * 8 + (slot)] = (long long)wall_clock64(); \
+    } while (0)
+extern "C" int pd_debug_pp_stamps(long long* out, int n_blocks) {
+    if (n_blocks < 0 || n_blocks > 4096) return PD_E_INVALID;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), (size_t)n_blocks * 8 * sizeof(long long)) == hipSuccess ? PD_OK : PD_E_HIP;
+}
+#else
+#define PP_STAMP(slot, cond) do { } while (0)
+#endif
 #define PP_CHUNK 256  // images whose person rows are placed per round of the last workgroup
 
 __global__ void __launch_bounds__(256)
@@ -637,6 +654,7 @@ k_parse_pack(ParsePackArgs a) {
     __shared__ int s_off[PP_CHUNK + 1], s_wsum[4], s_bad[4];
     const PackArgs& k = a.k;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    PP_STAMP(0, tid == 0);
     // every stage that reads the per-decode counters has run: leave them zero for the next decode
     if (k.zero)
         for (int i = b * 256 + tid; i < k.zero_words; i += gridDim.x * 256) k.zero[i] = 0;
@@ -653,6 +671,7 @@ k_parse_pack(ParsePackArgs a) {
         wave_parse_begin(sh, st, lane);
         wave_parse_limbs(a.p, b, lane, 0, PD_N_LIMBS, sh, st);
         wave_parse_end(a.p, b, lane, sh, st);
+        PP_STAMP(1, lane == 0);
     } else {
         const int w = wv - 1;
         long long pre_p = 0, tot_p = 0, pre_c = 0, tot_c = 0;
@@ -717,16 +736,19 @@ k_parse_pack(ParsePackArgs a) {
             PD_PUT(dst + 1, c1);
             PD_PUT(dst + 2, c2);
         }
+        PP_STAMP(1 + wv, lane == 0);
     }
     // this image's person rows, count and status were stored write-through and have arrived (the
     // wait below, in every wavefront, then the barrier); the last workgroup to get here goes on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PP_STAMP(5, tid == 0);
     if (tid == 0) {
         const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = t == (int)gridDim.x - 1;
     }
     __syncthreads();
+    PP_STAMP(6, tid == 0);
     if (!s_last) return;
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -795,6 +817,7 @@ k_parse_pack(ParsePackArgs a) {
         PD_PUT(head + 4, (int64_t)(fb == 0x7fffffff ? -1 : fb));
         PD_PUT(head + 5, (int64_t)0);  // the library's own buffer holds any result by construction
         __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PP_STAMP(7, true);
     }
 #undef PD_PUT
 }

@@ -429,14 +429,17 @@ def test_multiscale_average_and_decode(pdec, scales):
 
 @pytest.mark.parametrize('geom', [dict(H=200, W=312, scales=[0.5, 1.0, 1.5, 2.0]),      # pads in every scale, H != W
                                   dict(H=97, W=131, scales=[0.6, 1.0, 1.9]),            # odd sizes, three scales
-                                  dict(H=368, W=368, scales=[1.0])])                    # one scale: the average is the x8 map
+                                  dict(H=368, W=368, scales=[1.0]),                     # one scale: the average is the x8 map
+                                  # a COCO-sized image at predict.py:49's scales for 368 / 480: 80 cell columns (the
+                                  # general bound kernel) and staging areas beyond 64 KB of LDS
+                                  dict(H=480, W=640, scales=[0.38, 0.77, 1.15, 1.53], B=1, sparse=True)])
 def test_multiscale_decode_without_stored_maps(pdec, geom):
     """pd_decode_multiscale (predict.py:49-254 behind the network calls) on geometries with
     non-zero pads: against the oracle's upsample_average + decode and against the stored-maps
     form, in both modes."""
     from poseestimation_amd import synth
     H, W, scales = geom['H'], geom['W'], geom['scales']
-    B = 3
+    B = geom.get('B', 3)
     heats, pafs, pads = [], [], []
     for s in scales:
         sh, sw = int(round(H * s)), int(round(W * s))
@@ -450,6 +453,10 @@ def test_multiscale_decode_without_stored_maps(pdec, geom):
         eng.ctx.set_mode(pdec._MODES[mode])
         eng.mode = pdec._MODES[mode]
         res = eng.decode_multiscale(heats, pafs, pads, (H, W))
+        stats = eng.ctx.filter_stats()
+        if geom.get('sparse'):
+            # the sparse stage ran (its cell lists have no border kind), not the stored-maps form behind it
+            assert stats['cells_interior'] > 0 and stats['cells_border'] == 0 and stats['planes_exact'] == 0
         stored = eng.decode_multiscale(heats, pafs, pads, (H, W), materialise=True)
         for key in ('part_count', 'limb_count', 'person_count', 'peaks', 'conns', 'persons'):
             assert np.array_equal(res.packed[key], stored.packed[key]), (mode, key)

@@ -308,3 +308,55 @@ def test_bench_pairs_a_context_with_few_buffers_whatever_the_run_lengths():
                 seen.setdefault(count % n_ctx, set()).add(count % nbuf)
                 count += 1
         assert max(len(v) for v in seen.values()) <= 6, (n_ctx, nbuf, seen)
+
+
+@pytest.mark.parametrize('l,crop,L', [(23, 184, 368), (46, 368, 368), (69, 552, 368), (92, 736, 368),
+                                      (26, 203, 97), (13, 97, 97), (58, 460, 200), (40, 313, 361)])
+def test_multiscale_composite_operator_is_the_reference_pipeline(l, crop, L):
+    """The sparse multi-scale peak stage evaluates Gaussian o resize o x8-resize as one banded
+    operator per axis and scale.  The matrix the library builds (pd_test_ms_axis, host only) must
+    be that pipeline: applied to random 1-D signals it reproduces oracle resize_cubic twice +
+    the restated scipy filter; its cell form holds exactly its float32 weights, windows of at
+    most 16 sources, and bound weights that dominate every own output of a cell."""
+    import ctypes as C
+    from poseestimation_amd import _ffi
+    from oracle import decode_ref as ref
+    Lb = _ffi.lib()
+    identity = int(crop == L)
+    nc = (L + 7) // 8
+    K = np.zeros((L, l), np.float64)
+    cw = np.zeros((nc, 10, 16), np.float32)
+    bw = np.zeros((nc, 16), np.float32)
+    lo = np.zeros((nc,), np.int32)
+    factor = 0.25
+    widest = Lb.pd_test_ms_axis(l, crop, L, identity, factor, K.ctypes.data, cw.ctypes.data, bw.ctypes.data, lo.ctypes.data)
+    assert 1 <= widest <= 16
+    rng = np.random.RandomState(l * 1000 + L)
+    w = ref.gaussian_weights(3.0)
+    for trial in range(3):
+        src = rng.randn(l).astype(np.float32)
+        up = ref.resize_cubic(src.reshape(l, 1, 1), fx=1, fy=8)[:crop]              # predict.py:63-64 along one axis
+        if not identity:
+            up = ref.resize_cubic(np.ascontiguousarray(up), dst_hw=(L, 1))          # predict.py:65
+        want = ref._correlate_axis0(up[:, 0, 0].astype(np.float64), w) * factor
+        got = K @ src.astype(np.float64)
+        # (the reference rounds to float32 after every pass, the operator is its exact-arithmetic form)
+        assert np.max(np.abs(got - want)) <= 4e-6 * max(1.0, np.abs(src).max())
+    # the cell form: the same weights, rounded to float32, inside windows of 16
+    dense = np.zeros((L, l), np.float32)
+    for c in range(nc):
+        for j in range(10):
+            o = 8 * c - 1 + j
+            if 0 <= o < L:
+                for p in range(16):
+                    if cw[c, j, p] != 0:
+                        assert lo[c] + p < l
+                        dense[o, lo[c] + p] = cw[c, j, p]
+    for o in range(L):
+        c, j = o // 8, o % 8 + 1
+        row = np.zeros(l, np.float32)
+        row[lo[c]:lo[c] + 16] = cw[c, j, :min(16, l - lo[c])]
+        assert np.array_equal(row, K[o].astype(np.float32)), o
+    assert np.array_equal(bw, np.abs(cw[:, 1:9, :]).max(axis=1))
+    # a scale beyond what the sparse stage takes is refused, not truncated
+    assert Lb.pd_test_ms_axis(200, 1600, 368, 0, 1.0, None, None, None, None) == -1
