@@ -117,9 +117,10 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
     CR(dev_alloc(ctx, (void**)&ctx->raw, B * PD_N_PARTS * PK * sizeof(RawPeak)));
     // counters that start every decode at zero share one allocation and one memset
     ctx->zero_bytes = (2 * B * PD_N_PARTS + 96) * sizeof(int32_t);
-    CR(dev_alloc(ctx, (void**)&ctx->zero_block, ctx->zero_bytes + 64));  // + the arrival counter of the pack
-    CRH(hipMemset(ctx->zero_block, 0, ctx->zero_bytes + 64));
-    ctx->pack_ticket = ctx->zero_block + ctx->zero_bytes / sizeof(int32_t);
+    CR(dev_alloc(ctx, (void**)&ctx->zero_block, ctx->zero_bytes));
+    CRH(hipMemset(ctx->zero_block, 0, ctx->zero_bytes));
+    CR(dev_alloc(ctx, (void**)&ctx->pack_sync, (16 + B) * sizeof(int32_t)));  // arrival counter, tag, a word per image
+    CRH(hipMemset(ctx->pack_sync, 0, (16 + B) * sizeof(int32_t)));
     ctx->zero_clean = 1;
     CR(dev_alloc(ctx, (void**)&ctx->full_absmax, B * sizeof(float)));
     CR(dev_alloc(ctx, (void**)&ctx->plane_slack, B * PD_N_PARTS * sizeof(float2)));
@@ -195,7 +196,7 @@ extern "C" int pd_destroy(pd_ctx* ctx) {
                     ctx->pair_score, ctx->conn, ctx->conn_conf, ctx->limb_count, ctx->persons,
                     ctx->person_count, ctx->status, ctx->res_dev, ctx->kf_tab, ctx->kf_reg, ctx->cells, ctx->cand,
                     ctx->heat_planar, ctx->paf_pairs, ctx->fstats, ctx->full_absmax, ctx->aux_dev, ctx->dbg_found, ctx->plane_slack,
-                    ctx->msf_tab, ctx->msf_lo, ctx->ms_planar, ctx->ms_dev};
+                    ctx->msf_tab, ctx->msf_lo, ctx->ms_planar, ctx->ms_dev, ctx->pack_sync};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (TableSlot& t : ctx->tabs) {

@@ -212,7 +212,7 @@ struct pd_ctx {
     int destroy_pending;  // pd_destroy was called while sharers were left: freed with the last of them
     hipEvent_t done_ev;   // recorded behind every whole decode of a context whose stream carries two contexts
     int done_valid;       // done_ev marks the end of everything this context has queued
-    int32_t* pack_ticket; // behind the block: arrival counter of k_parse_pack, zero between launches (NULL: not available)
+    int32_t* pack_sync;   // k_parse_pack's arrival counter, tag and one published word per image (NULL: not available)
     int64_t* fstats;     // what pd_filter_stats reports, summed up by k_sort_peaks before the counters go
     RawPeak* raw;        // [B][18][PK] unordered
     int32_t* raw_count;  // [B][18]

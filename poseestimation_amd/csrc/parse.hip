@@ -33,8 +33,9 @@ __device__ __forceinline__ void put_out(int32_t* p, int32_t v) {
 }
 
 // The table form for image b; tab holds max_persons rows of 20 doubles in LDS.  Run by one
-// wavefront (its lanes are ordered among themselves with pd_wave_sync).
-__device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
+// wavefront (its lanes are ordered among themselves with pd_wave_sync).  Returns the number of
+// person rows it wrote.
+__device__ int parse_table(const ParseArgs& a, int b, int lane, double* tab) {
     int n = 0;           // live rows
     int err = PD_OK;
     // the limb's connection counts, one per lane, fetched once
@@ -133,6 +134,7 @@ __device__ void parse_table(const ParseArgs& a, int b, int lane, double* tab) {
         put_out(a.person_count + b, err == PD_E_INDEX ? 0 : kept);
         if (err != PD_OK && a.status[b] == PD_OK) put_out(a.status + b, err);
     }
+    return err == PD_E_INDEX ? 0 : kept;
 }
 
 __global__ void __launch_bounds__(64)
@@ -159,13 +161,25 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// What a connection hands the person it extends or opens; tagged with its limb.
+struct WaveRec {
+    int ab;     // id_a << 16 | id_b
+    int meta;   // (limb + 1) << 8 | REC_NEW | connection
+    double sc;  // extension: conf_b + score; new person: (conf_a + conf_b) + score
+};
+#define REC_NEW 0x80
+#define REC_CONN 0x3f
+#define REC_TAG 0x1f00
+
 // The wavefront's LDS.
 struct WaveShared {
     int ids[PD_N_PARTS][64];
     __attribute__((aligned(16))) double c_all[WAVE_CONNS * 4];  // staged connections; the table form's rows on hand-over
-    short tab_a[WAVE_IDS], tab_b[WAVE_IDS];  // peak id -> connection of the current limb
-    short own[64];                           // connection -> the person that matches it
-    short newc[64];                          // new person slot -> its connection
+    __attribute__((aligned(16))) WaveRec rec[64];  // person (lane) <- the connection that matches its near end, or opens it
+    short rec_b[64];                 // person <- the connection that matches its far end: (limb + 1) << 8 | connection
+    short who[WAVE_IDS];             // peak id -> the person that holds it (-1: nobody); exact while every limb went the fast way
+    short chk[WAVE_IDS];             // peak id -> connection of the current limb (written and read back by the same lanes)
+    unsigned char part_of[WAVE_IDS]; // peak id -> the part it was seen as (0xff: not seen)
 };
 
 // What the wavefront carries from limb to limb.
@@ -175,14 +189,16 @@ struct WaveState {
     int n;       // open persons
     int rc;      // 0 go on, 1 hand the image to the table form, 2 mode-D index error
     int staged;  // connections staged so far
+    int by_id;   // the lookup by peak id is valid: ids in range, every id one part's, no limb went through the loop yet
 };
 
 __device__ __forceinline__ void wave_parse_begin(WaveShared& sh, WaveState& st, int lane) {
-    for (int i = lane; i < WAVE_IDS; i += 64) {
-        sh.tab_a[i] = -1;
-        sh.tab_b[i] = -1;
-    }
-    sh.own[lane] = -1;
+    int* who2 = (int*)sh.who;
+    for (int i = lane; i < WAVE_IDS / 2; i += 64) who2[i] = -1;
+    int* part4 = (int*)sh.part_of;
+    for (int i = lane; i < WAVE_IDS / 4; i += 64) part4[i] = -1;
+    sh.rec[lane].meta = 0;
+    sh.rec_b[lane] = 0;
 #pragma unroll
     for (int p = 0; p < PD_N_PARTS; ++p) sh.ids[p][lane] = -1;
     st.my_score = 0.0;
@@ -190,8 +206,32 @@ __device__ __forceinline__ void wave_parse_begin(WaveShared& sh, WaveState& st, 
     st.n = 0;
     st.rc = 0;
     st.staged = 0;
+    st.by_id = 1;
     pd_wave_sync();
 }
+
+// Measurement build only (-DPP_STAMPS, tools/parse_pack_split.py): where a workgroup's time goes.
+// Per workgroup, in units of the 100 MHz wall clock: start, image number drawn, row count known
+// (assembly done), each copy wavefront done, look-back done, rows written, (last image) header written;
+// 8: connections staged, 9: limbs applied.
+#ifdef PP_STAMPS
+__device__ long long g_pp_stamps[4096 * 16];
+#define PP_STAMP(slot, cond)                                               \
+    do {                                                                   \
+        if ((cond) && blockIdx.x < 4096) g_pp_stamps[blockIdx.x * 16 + (slot)] = (long long)wall_clock64(); \
+    } while (0)
+extern "C" int pd_debug_pp_stamps(long long* out, int n_blocks) {
+    if (n_blocks < 0 || n_blocks > 4096) return PD_E_INVALID;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), (size_t)n_blocks * 16 * sizeof(long long)) == hipSuccess ? PD_OK : PD_E_HIP;
+}
+#define PP_NOTE(slot, cond, value)                                         \
+    do {                                                                   \
+        if ((cond) && blockIdx.x < 4096) g_pp_stamps[blockIdx.x * 16 + (slot)] = (long long)(value); \
+    } while (0)
+#else
+#define PP_STAMP(slot, cond) do { } while (0)
+#define PP_NOTE(slot, cond, value) do { } while (0)
+#endif
 
 // Limbs k0 .. k1-1 of image b: their connections are staged into LDS behind the ones staged
 // before (one round trip to memory), then applied in limb order.
@@ -221,14 +261,17 @@ __device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int 
     const int at0 = st.staged;  // where this call's connections start in the staging area
     // four connections per lane in flight, the limb of a flat index found from the prefix
     // sums held across the lanes
+    bool id_trouble = false;  // an id out of range or seen as two different parts: no lookup by id for this image
     for (int i0 = 0; i0 < total; i0 += 256) {
         pd_conn r[4];
         double cf0[4], cf1[4];
+        int pa_u[4], pb_u[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * 64 + lane;
             r[u].id_a = r[u].id_b = 0;
             r[u].score = cf0[u] = cf1[u] = 0.0;
+            pa_u[u] = pb_u[u] = 0;
             if (i < total) {
                 // limbs without connections share their offset with the next one: the scan
                 // lands on the last limb whose offset is <= i, which is the one that holds i
@@ -246,103 +289,138 @@ __device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int 
                 r[u] = a.conn[at];
                 cf0[u] = a.conn_conf[2 * at];
                 cf1[u] = a.conn_conf[2 * at + 1];
+                pa_u[u] = pd_limb_from(k);
+                pb_u[u] = pd_limb_to(k);
             }
         }
+        bool ranged[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * 64 + lane;
+            ranged[u] = false;
             if (i < total) {
                 c_ida[at0 + i] = r[u].id_a;
                 c_idb[at0 + i] = r[u].id_b;
                 c_score[at0 + i] = r[u].score;
                 c_ca[at0 + i] = cf0[u];
                 c_cb[at0 + i] = cf1[u];
+                ranged[u] = r[u].id_a >= 0 && r[u].id_a < WAVE_IDS && r[u].id_b >= 0 && r[u].id_b < WAVE_IDS;
+                if (!ranged[u]) id_trouble = true;
+                // the part an id stands for: as seen by the rounds before ...
+                if (ranged[u]) {
+                    const int sa = sh.part_of[r[u].id_a], sb = sh.part_of[r[u].id_b];
+                    if ((sa != 0xff && sa != pa_u[u]) || (sb != 0xff && sb != pb_u[u])) id_trouble = true;
+                }
             }
         }
+        pd_wave_sync();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ranged[u]) {
+                sh.part_of[r[u].id_a] = (unsigned char)pa_u[u];
+                sh.part_of[r[u].id_b] = (unsigned char)pb_u[u];
+            }
+        pd_wave_sync();
+        // ... and by this round (of two lanes that wrote different parts, one reads the other's)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ranged[u] && (sh.part_of[r[u].id_a] != pa_u[u] || sh.part_of[r[u].id_b] != pb_u[u])) id_trouble = true;
     }
+    if (__ballot(id_trouble) != 0ull) st.by_id = 0;
     st.staged += total;
     pd_wave_sync();
+    PP_STAMP(8, lane == 0);
     double my_score = st.my_score;
     int my_cnt = st.my_cnt;
     int n = st.n;
     int rc = 0;
+    int by_id = st.by_id;
+    int dbg_fast = 0, dbg_limbs = 0;
+    const long long dbg_c0 = (long long)clock64();
+    const int my_pa = pd_limb_from(min(lane, PD_N_LIMBS - 1)), my_pb = pd_limb_to(min(lane, PD_N_LIMBS - 1));
     for (int k = k0; k < k1 && rc == 0; ++k) {
         const int nc = __builtin_amdgcn_readlane(my_nc, k), o = at0 + __builtin_amdgcn_readlane(off, k);
         if (nc == 0) continue;
-        const int pa = pd_limb_from(k), pb = pd_limb_to(k);
-        // the two id columns this limb tests stay in registers for the whole limb; LDS
-        // is written through and only re-read around the (rare) merges
-        int col_a = sh.ids[pa][lane], col_b = sh.ids[pb][lane];
-        // Whole limb at once.  When every connection of the limb has its own two peaks
-        // (always so for connections that come from the matching stage), every person
-        // matches at most one connection and every connection at most one person, the
-        // sequential loop below would touch disjoint persons: each matched person takes
-        // its connection's end, each unmatched connection opens a person, in connection
-        // order.  Anything else (shared peaks, two owners, merges) takes the loop.
-        if (nc <= 64) {
+        ++dbg_limbs;
+        const int pa = __builtin_amdgcn_readlane(my_pa, k), pb = __builtin_amdgcn_readlane(my_pb, k);
+        // Whole limb at once, one lane per connection and one per person.  When no two connections
+        // of the limb share a peak (always so for connections that come from the matching
+        // stage), no person matches two different connections and no connection two different
+        // persons, the sequential loop below would touch disjoint persons: each person whose
+        // near end matches takes its connection's far end, each unmatched connection opens a
+        // person, in connection order.  A connection finds its persons through the table
+        // peak id -> person, which the fast way keeps exact; anything else (shared peaks, two
+        // owners, merges, ids out of range) takes the loop, for this limb and all after it.
+        if (by_id && nc <= 64) {
             const bool is_c = lane < nc;
-            const int ida = is_c ? c_ida[o + lane] : 0, idb = is_c ? c_idb[o + lane] : 0;
-            const bool in_range = !is_c || (ida >= 0 && ida < WAVE_IDS && idb >= 0 && idb < WAVE_IDS);
-            bool fast = __ballot(!in_range) == 0ull;
+            const int ci = min(o + lane, WAVE_CONNS - 1);
+            const int ida = is_c ? c_ida[ci] : 0, idb = is_c ? c_idb[ci] : 0;
+            const double l_score = c_score[ci], l_ca = c_ca[ci], l_cb = c_cb[ci];
+            if (is_c) {
+                sh.chk[ida] = (short)lane;
+                sh.chk[idb] = (short)lane;
+            }
+            pd_wave_sync();
+            const int wa = is_c ? sh.who[ida] : -1, wb = is_c ? sh.who[idb] : -1;
+            const bool dup = is_c && (sh.chk[ida] != lane || sh.chk[idb] != lane);
+            const bool shared_conn = wa >= 0 && wb >= 0 && wa != wb;
+            const bool unmatched = is_c && wa < 0 && wb < 0;
+            const unsigned long long um = __ballot(unmatched);
+            const int n_new = (a.mode == PD_MODE_D || k < 17) ? __builtin_popcountll(um) : 0;
+            const int tag = (k + 1) << 8;
+            if (is_c) {
+                WaveRec r;
+                r.ab = (ida << 16) | idb;
+                if (wa >= 0) {
+                    r.meta = tag | lane;
+                    r.sc = l_cb + l_score;  // :210 / predict.py:205
+                    sh.rec[wa] = r;
+                }
+                if (wb >= 0) sh.rec_b[wb] = (short)(tag | lane);
+                const int slot = n + __builtin_popcountll(um & ((1ull << lane) - 1ull));
+                if (unmatched && n_new > 0 && slot < 64) {
+                    r.meta = tag | REC_NEW | lane;
+                    r.sc = (l_ca + l_cb) + l_score;  // utils/postprocess.py:196-205 / predict.py:228-244
+                    sh.rec[slot] = r;
+                }
+            }
+            pd_wave_sync();
+            const WaveRec mine_rec = sh.rec[lane];
+            const int mine_b = sh.rec_b[lane];
+            const int col_b = sh.ids[pb][lane];
+            const bool got_a = lane < n && (mine_rec.meta & REC_TAG) == tag && !(mine_rec.meta & REC_NEW);
+            const bool got_b = lane < n && (mine_b & REC_TAG) == tag;
+            const bool two = got_a && got_b && (mine_rec.meta & REC_CONN) != (mine_b & REC_CONN);
+            const bool fast = __ballot(dup || shared_conn || two) == 0ull;
             if (fast) {
-                if (is_c) {
-                    sh.tab_a[ida] = (short)lane;
-                    sh.tab_b[idb] = (short)lane;
-                }
-                pd_wave_sync();
-                const bool dup = is_c && (sh.tab_a[ida] != lane || sh.tab_b[idb] != lane);
-                const bool is_p = lane < n;
-                const int ca = (is_p && col_a >= 0 && col_a < WAVE_IDS) ? sh.tab_a[col_a] : -1;
-                const int cb = (is_p && col_b >= 0 && col_b < WAVE_IDS) ? sh.tab_b[col_b] : -1;
-                const bool two = ca >= 0 && cb >= 0 && ca != cb;
-                const int mc = ca >= 0 ? ca : cb;
-                if (mc >= 0) sh.own[mc] = (short)lane;
-                pd_wave_sync();
-                const bool shared_conn = mc >= 0 && sh.own[mc] != lane;
-                fast = __ballot(dup || two || shared_conn) == 0ull;
-                const bool unmatched = is_c && sh.own[lane] < 0;
-                const unsigned long long um = __ballot(unmatched);
-                const int n_new = (a.mode == PD_MODE_D || k < 17) ? __builtin_popcountll(um) : 0;
-                const bool room = n + n_new <= 64 && n + n_new <= a.max_persons;
-                if (fast && room) {
-                    if (mc >= 0) {
-                        const int tb = c_idb[o + mc];
-                        if (col_b != tb) {  // :210 / predict.py:205
-                            col_b = tb;
-                            sh.ids[pb][lane] = tb;
-                            my_cnt += 1;
-                            my_score += c_cb[o + mc] + c_score[o + mc];
-                        }
-                    }
-                    if (n_new > 0) {
-                        if (unmatched) sh.newc[__builtin_popcountll(um & ((1ull << lane) - 1ull))] = (short)lane;
-                        pd_wave_sync();
-                        if (lane >= n && lane < n + n_new) {  // utils/postprocess.py:196-205 / predict.py:228-244
-                            const int c = sh.newc[lane - n];
-                            col_a = c_ida[o + c];
-                            col_b = c_idb[o + c];
-                            sh.ids[pa][lane] = col_a;
-                            sh.ids[pb][lane] = col_b;
-                            my_score = (c_ca[o + c] + c_cb[o + c]) + c_score[o + c];
-                            my_cnt = 2;
-                        }
-                        n += n_new;
-                    }
-                }
-                // leave the tables clean for the next limb
-                if (is_c) {
-                    sh.tab_a[ida] = -1;
-                    sh.tab_b[idb] = -1;
-                }
-                sh.own[lane] = -1;
-                pd_wave_sync();
-                if (fast && room) continue;
-                if (fast && !room) {  // more than 64 open persons: the table form takes the image
+                if (n + n_new > 64 || n + n_new > a.max_persons) {  // more open persons than lanes: the table form takes the image
                     rc = 1;
                     break;
                 }
+                const int tb = mine_rec.ab & 0xffff;
+                if (got_a && col_b != tb) {
+                    sh.ids[pb][lane] = tb;
+                    sh.who[tb] = (short)lane;
+                    my_cnt += 1;
+                    my_score += mine_rec.sc;
+                }
+                if (lane >= n && lane < n + n_new) {
+                    const int ta = mine_rec.ab >> 16;
+                    sh.ids[pa][lane] = ta;
+                    sh.ids[pb][lane] = tb;
+                    sh.who[ta] = (short)lane;
+                    sh.who[tb] = (short)lane;
+                    my_score = mine_rec.sc;
+                    my_cnt = 2;
+                }
+                n += n_new;
+                ++dbg_fast;
+                pd_wave_sync();
+                continue;
             }
         }
+        by_id = 0;  // the loop does not keep the table peak id -> person
+        int col_a = sh.ids[pa][lane], col_b = sh.ids[pb][lane];
         for (int c0 = 0; c0 < nc && rc == 0; c0 += 64) {
             // this chunk's connections, one per lane, broadcast below with readlane
             const int mine_at = min(o + c0 + lane, WAVE_CONNS - 1);
@@ -429,38 +507,62 @@ __device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int 
     st.my_cnt = my_cnt;
     st.n = n;
     st.rc = rc;
+    st.by_id = by_id;
+    PP_STAMP(9, lane == 0);
+    PP_NOTE(10, lane == 0, dbg_fast);
+    PP_NOTE(11, lane == 0, dbg_limbs);
+    PP_NOTE(12, lane == 0, total);
+    PP_NOTE(13, lane == 0, (long long)clock64() - dbg_c0);
 }
 
-// Prune and write out, or hand the image over.
-__device__ __forceinline__ void wave_parse_end(const ParseArgs& a, int b, int lane, WaveShared& sh, WaveState& st) {
+// Prune (:228-232 / predict.py:248-252), or hand the image over.  Returns the number of person
+// rows of the image (-1: left to k_parse) and stores it.  direct: the rows are still with the
+// lanes -- lane j with keep holds row number rank -- and wave_write_row puts them where the
+// caller wants them; otherwise the table form has written them to the staging area already.
+__device__ __forceinline__ int wave_parse_prune(const ParseArgs& a, int b, int lane, WaveShared& sh, WaveState& st, bool& keep,
+                                                int& rank, bool& direct) {
+    keep = false;
+    rank = 0;
+    direct = false;
     if (st.rc == 1) {  // more connections or open persons than the wavefront form holds: the table form redoes this image
         if (a.only_flagged) {
             if (lane == 0) put_out(a.person_count + b, -1);
-        } else {
-            pd_wave_sync();
-            parse_table(a, b, lane, sh.c_all);
+            return -1;
         }
-        return;
+        pd_wave_sync();
+        return parse_table(a, b, lane, sh.c_all);
     }
     if (st.rc == 2) {
         if (lane == 0) {
             put_out(a.person_count + b, 0);
             if (a.status[b] == PD_OK) put_out(a.status + b, (int32_t)PD_E_INDEX);
         }
-        return;
+        return 0;
     }
-    // prune (:228-232 / predict.py:248-252) and write out in row order
-    bool keep = false;
     if (lane < st.n) keep = !((double)st.my_cnt < 4.0 || st.my_score / (double)st.my_cnt < 0.4);
     const unsigned long long m = __ballot(keep);
-    if (keep) {
-        double* out = a.persons + ((size_t)b * a.max_persons + __builtin_popcountll(m & ((1ull << lane) - 1ull))) * 20;
+    rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    direct = true;
+    const int kept = __builtin_popcountll(m);
+    if (lane == 0) put_out(a.person_count + b, (int32_t)kept);
+    return kept;
+}
+
+// The row of this lane's person (18 part ids, score, part count) to out and, if mirror != 0, to
+// the same place mirror bytes further on.
+__device__ __forceinline__ void wave_write_row(double* out, long long mirror, int lane, const WaveShared& sh, const WaveState& st) {
+    double v[20];
 #pragma unroll
-        for (int p = 0; p < PD_N_PARTS; ++p) put_out(out + p, (double)sh.ids[p][lane]);
-        put_out(out + 18, st.my_score);
-        put_out(out + 19, (double)st.my_cnt);
+    for (int p = 0; p < PD_N_PARTS; ++p) v[p] = (double)sh.ids[p][lane];
+    v[18] = st.my_score;
+    v[19] = (double)st.my_cnt;
+#pragma unroll
+    for (int q = 0; q < 20; ++q) out[q] = v[q];
+    if (mirror != 0) {
+        double* out2 = (double*)((unsigned char*)out + mirror);
+#pragma unroll
+        for (int q = 0; q < 20; ++q) out2[q] = v[q];
     }
-    if (lane == 0) put_out(a.person_count + b, (int32_t)__builtin_popcountll(m));
 }
 
 __global__ void __launch_bounds__(64)
@@ -470,7 +572,10 @@ k_parse_wave(ParseArgs a) {
     WaveState st;
     wave_parse_begin(sh, st, lane);
     wave_parse_limbs(a, b, lane, 0, PD_N_LIMBS, sh, st);
-    wave_parse_end(a, b, lane, sh, st);
+    bool keep, direct;
+    int rank;
+    wave_parse_prune(a, b, lane, sh, st, keep, rank, direct);
+    if (direct && keep) wave_write_row(a.persons + ((size_t)b * a.max_persons + rank) * 20, 0, lane, sh, st);
 }
 
 // ---- packing --------------------------------------------------------------------
@@ -614,47 +719,57 @@ k_pack(PackArgs a) {
 // One workgroup of four wavefronts per image.  Wavefront 0 assembles the persons of the image
 // (the body of k_parse_wave); meanwhile the other three, each on its own, sum the peak and
 // connection counts of all images (which the earlier launches left complete) and copy this
-// image's count tables, peaks and connections to their places in the result buffer.  The
-// person rows can only be placed once every image's person count is known: each workgroup
-// stores its rows write-through at agent scope and draws a ticket; the workgroup that draws the
-// last one (agent-scope acquire) writes the person rows of all images, the person / status tables and
-// the header.  The ticket word is zero between launches (the last workgroup resets it).
+// image's count tables, peaks and connections to their places in the result buffer.
+//
+// The person rows of an image start behind those of all images before it.  As soon as wavefront
+// 0 knows its image's row count it publishes (tag | not-ok bit | count) in a word of its own and
+// then reads the words of all images before it, waiting for those not published yet (a
+// decoupled look-back: nobody waits for a later image).  It then writes its rows from its
+// registers straight to their place.  The image a workgroup works on is the number it draws from
+// an arrival counter, not its position in the grid: every image a workgroup waits for therefore
+// belongs to a workgroup that is already running, whatever the order the hardware starts them in.
+// The workgroup of the last image has seen every count: it writes the header, gives the words of
+// the images beyond this batch the tag as well and stores the tag for the next launch, whose tag
+// differs -- every word always carries the previous launch's tag, so no word needs clearing.
 struct ParsePackArgs {
     ParseArgs p;
     PackArgs k;
-    int32_t* ticket;
+    int32_t* sync;  // [0] arrival counter (zero between launches), [1] tag of the last launch, [PP_WORDS + j] word of image j
+    int max_batch;  // words behind PP_WORDS
 };
 
 static_assert(sizeof(pd_conn) == 24, "k_parse_pack copies a connection as three 8-byte words");
+#define PP_WORDS 16            // ints in front of the published words
+#define PP_NOT_OK 512          // bit of a published word: the image's status is not PD_OK
+#define PP_TAG_SHIFT 10        // the tag sits above count (< 512) and PP_NOT_OK
+#define PP_TAG_MASK 0x1fffff
 
-// Measurement build only (-DPP_STAMPS, tools/parse_pack_split.py): where a workgroup's time goes.
-// Per workgroup, in units of the 100 MHz wall clock: start, assembly wavefront done, each copy
-// wavefront done, past the barrier, ticket drawn, (last workgroup) person rows placed.
-#ifdef PP_STAMPS
-__device__ long long g_pp_stamps[4096 * 8];
-#define PP_STAMP(slot, cond)                                               \
-    do {                                                                   \
-        if ((cond) && blockIdx.x < 4096) g_pp_stamps[blockIdx.x * 8 + (slot)] = (long long)wall_clock64(); \
-    } while (0)
-extern "C" int pd_debug_pp_stamps(long long* out, int n_blocks) {
-    if (n_blocks < 0 || n_blocks > 4096) return PD_E_INVALID;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), (size_t)n_blocks * 8 * sizeof(long long)) == hipSuccess ? PD_OK : PD_E_HIP;
-}
-#else
-#define PP_STAMP(slot, cond) do { } while (0)
-#endif
-#define PP_CHUNK 256  // images whose person rows are placed per round of the last workgroup
 
 __global__ void __launch_bounds__(256)
 k_parse_pack(ParsePackArgs a) {
     __shared__ WaveShared sh;
     __shared__ int s_pb[3][PD_N_PARTS + 1], s_lb[3][PD_N_LIMBS + 1];
     __shared__ long long s_tot[2];
-    __shared__ int s_last;
-    __shared__ int s_off[PP_CHUNK + 1], s_wsum[4], s_bad[4];
+    __shared__ int s_b, s_tag;
     const PackArgs& k = a.k;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     PP_STAMP(0, tid == 0);
+    WaveState st;
+    int t = 0, last_tag = 0;
+    if (tid == 0) {
+        t = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the workgroup that stores the new tag does so after every other one has published, so after this load)
+        last_tag = __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wv == 0) wave_parse_begin(sh, st, lane);  // (while the two answers are on their way)
+    if (tid == 0) {
+        if (t == (int)gridDim.x - 1) __hip_atomic_store(a.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all have drawn
+        s_b = t;
+        s_tag = (last_tag + 1) & PP_TAG_MASK;
+    }
+    __syncthreads();
+    const int b = s_b, tag = s_tag;
+    PP_STAMP(1, tid == 0);
     // every stage that reads the per-decode counters has run: leave them zero for the next decode
     if (k.zero)
         for (int i = b * 256 + tid; i < k.zero_words; i += gridDim.x * 256) k.zero[i] = 0;
@@ -666,12 +781,37 @@ k_parse_pack(ParsePackArgs a) {
         *p_ = v_;                                                         \
         if (k.res2) *(decltype(p_))((unsigned char*)p_ + mirror) = v_;    \
     } while (0)
+    bool keep = false, direct = false;
+    int rank = 0, count = 0, stv = PD_OK;
+    long long pre = 0;  // person rows of the images before this one
+    int bad = 0x7fffffff;
     if (wv == 0) {
-        WaveState st;
-        wave_parse_begin(sh, st, lane);
         wave_parse_limbs(a.p, b, lane, 0, PD_N_LIMBS, sh, st);
-        wave_parse_end(a.p, b, lane, sh, st);
-        PP_STAMP(1, lane == 0);
+        count = wave_parse_prune(a.p, b, lane, sh, st, keep, rank, direct);
+        // (lane 0 may have stored this status itself just now: same lane, same address, in order)
+        stv = __builtin_amdgcn_readfirstlane(lane == 0 ? __hip_atomic_load(a.p.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+        if (lane == 0)
+            __hip_atomic_store(a.sync + PP_WORDS + b, (tag << PP_TAG_SHIFT) | (stv != PD_OK ? PP_NOT_OK : 0) | count, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        PP_STAMP(2, lane == 0);
+        if (stv != PD_OK) bad = b;
+        int rows = 0;
+        for (int j = lane; j < b; j += 64) {
+            int v = __hip_atomic_load(a.sync + PP_WORDS + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((v >> PP_TAG_SHIFT) != tag) {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(a.sync + PP_WORDS + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            rows += v & (PP_NOT_OK - 1);
+            if (v & PP_NOT_OK) bad = min(bad, j);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            rows += __shfl_xor(rows, d);
+            bad = min(bad, __shfl_xor(bad, d));
+        }
+        pre = rows;
+        PP_STAMP(6, lane == 0);
     } else {
         const int w = wv - 1;
         long long pre_p = 0, tot_p = 0, pre_c = 0, tot_c = 0;
@@ -736,89 +876,45 @@ k_parse_pack(ParsePackArgs a) {
             PD_PUT(dst + 1, c1);
             PD_PUT(dst + 2, c2);
         }
-        PP_STAMP(1 + wv, lane == 0);
+        PP_STAMP(2 + wv, lane == 0);
     }
-    // this image's person rows, count and status were stored write-through and have arrived (the
-    // wait below, in every wavefront, then the barrier); the last workgroup to get here goes on
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    PP_STAMP(5, tid == 0);
-    if (tid == 0) {
-        const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    PP_STAMP(6, tid == 0);
-    if (!s_last) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
+    __syncthreads();  // the totals of peaks and connections (wavefront 1) reach wavefront 0
+    if (wv != 0) return;
     const long long n_peaks = s_tot[0], n_conns = s_tot[1];
-    double* out_persons = (double*)(k.res + k.lay.off_payload + n_peaks * sizeof(pd_peak) + n_conns * sizeof(pd_conn));
-    long long rows_before = 0;  // person rows of the images of earlier rounds
-    int bad = 0x7fffffff;
-    for (int j0 = 0; j0 < k.B; j0 += PP_CHUNK) {
-        const int j = j0 + tid;
-        int c = 0;
-        if (j < k.B) {
-            c = k.person_count[j];
-            const int stj = k.status[j];
-            PD_PUT((int32_t*)(k.res + k.lay.off_pers) + j, c);
-            PD_PUT((int32_t*)(k.res + k.lay.off_stat) + j, stj);
-            if (stj != PD_OK) bad = min(bad, j);
+    double* out_persons = (double*)(k.res + k.lay.off_payload + n_peaks * sizeof(pd_peak) + n_conns * sizeof(pd_conn)) + pre * 20;
+    double* staged = a.p.persons + (size_t)b * a.p.max_persons * 20;
+    if (direct) {
+        if (keep) {
+            wave_write_row(staged + (size_t)rank * 20, 0, lane, sh, st);
+            wave_write_row(out_persons + (size_t)rank * 20, mirror, lane, sh, st);
         }
-        int incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
+    } else if (count > 0) {
+        // the table form left the rows in the staging area (stored write-through; drained here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int i = lane; i < count * 20; i += 64) {
+            const unsigned long long v = __hip_atomic_load((const unsigned long long*)staged + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PD_PUT((unsigned long long*)out_persons + i, v);
         }
-        if (lane == 63) s_wsum[wv] = incl;
-        __syncthreads();
-        int wbase = 0;
-        for (int q = 0; q < wv; ++q) wbase += s_wsum[q];
-        s_off[tid] = wbase + incl - c;
-        const int rows = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-        if (tid == 0) s_off[PP_CHUNK] = rows;
-        __syncthreads();
-        for (int r = tid; r < rows; r += 256) {
-            int lo = 0, hi = PP_CHUNK;  // last image of the round whose first row is <= r
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_off[mid] <= r)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const double* src = k.persons + ((size_t)(j0 + lo) * k.max_persons + (r - s_off[lo])) * 20;
-            double* dst = out_persons + (rows_before + r) * 20;
-            double v[20];
-#pragma unroll
-            for (int q = 0; q < 20; ++q) v[q] = src[q];
-#pragma unroll
-            for (int q = 0; q < 20; ++q) PD_PUT(dst + q, v[q]);
-        }
-        rows_before += rows;
-        __syncthreads();
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) bad = min(bad, __shfl_xor(bad, d));
-    if (lane == 0) s_bad[wv] = bad;
-    __syncthreads();
-    if (tid == 0) {
-        int64_t* head = (int64_t*)k.res;
-        const int fb = min(min(s_bad[0], s_bad[1]), min(s_bad[2], s_bad[3]));
-        PD_PUT(head + 0, (int64_t)k.B);
-        PD_PUT(head + 1, (int64_t)n_peaks);
-        PD_PUT(head + 2, (int64_t)n_conns);
-        PD_PUT(head + 3, (int64_t)rows_before);
-        PD_PUT(head + 4, (int64_t)(fb == 0x7fffffff ? -1 : fb));
-        PD_PUT(head + 5, (int64_t)0);  // the library's own buffer holds any result by construction
-        __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        PP_STAMP(7, true);
+    if (lane == 0) {
+        PD_PUT((int32_t*)(k.res + k.lay.off_pers) + b, (int32_t)count);
+        PD_PUT((int32_t*)(k.res + k.lay.off_stat) + b, (int32_t)stv);
     }
+    if (b == (int)gridDim.x - 1) {
+        if (lane == 0) {
+            int64_t* head = (int64_t*)k.res;
+            PD_PUT(head + 0, (int64_t)k.B);
+            PD_PUT(head + 1, (int64_t)n_peaks);
+            PD_PUT(head + 2, (int64_t)n_conns);
+            PD_PUT(head + 3, (int64_t)(pre + count));
+            PD_PUT(head + 4, (int64_t)(bad == 0x7fffffff ? -1 : bad));
+            PD_PUT(head + 5, (int64_t)0);  // the library's own buffer holds any result by construction
+        }
+        for (int j = k.B + lane; j < a.max_batch; j += 64)
+            __hip_atomic_store(a.sync + PP_WORDS + j, tag << PP_TAG_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(a.sync + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    PP_STAMP(7, lane == 0);
 #undef PD_PUT
 }
 
@@ -887,9 +983,9 @@ bool pd_parse_pack_fused(const pd_ctx* ctx) {
         const char* v = getenv("PD_SEPARATE_PACK");
         return v && *v && *v != '0';
     }();
-    return !separate && ctx->pack_direct && ctx->pack_ticket && ctx->impl != PD_IMPL_SIMPLE && !ctx->dbg_found && !ctx->skel_dst &&
+    return !separate && ctx->pack_direct && ctx->pack_sync && ctx->impl != PD_IMPL_SIMPLE && !ctx->dbg_found && !ctx->skel_dst &&
            ctx->host_results && ctx->res_user_cap == 0 && ctx->have_peaks && ctx->have_conns &&
-           (size_t)ctx->cfg.max_persons * 20 <= (size_t)WAVE_CONNS * 4;
+           (size_t)ctx->cfg.max_persons * 20 <= (size_t)WAVE_CONNS * 4 && ctx->cfg.max_persons < PP_NOT_OK;
 }
 
 int pd_launch_parse_pack(pd_ctx* ctx) {
@@ -907,7 +1003,8 @@ int pd_launch_parse_pack(pd_ctx* ctx) {
     a.p.dbg_found = nullptr;
     ctx->have_persons = 1;
     fill_pack_args(ctx, a.k);
-    a.ticket = ctx->pack_ticket;
+    a.sync = ctx->pack_sync;
+    a.max_batch = ctx->cfg.max_batch;
     pd_prof_begin(ctx, PD_STAGE_PARSE);
     hipLaunchKernelGGL(k_parse_pack, dim3(ctx->B), dim3(256), 0, ctx->stream, a);
     pd_prof_end(ctx);

@@ -114,6 +114,80 @@ def test_parse_more_than_64_open_persons(pp):
         gio.assert_persons_equal(ctx.fetch()['persons'], want, RTOL)
 
 
+def _assembly_case(rng, kind):
+    """Peaks and connections for multi_person_parse: `people` skeletons with parts dropped at
+    random; kind says how the connections are drawn."""
+    people = int(rng.randint(1, 9))
+    base = 3000 if kind == 'big_ids' else 0
+    peaks, pid = [], base
+    for part in range(18):
+        n = people if kind != 'ragged' else int(rng.randint(0, people + 1))
+        if kind == 'reused_ids':
+            pid = 0                                     # every part numbers its peaks from 0
+        # (the confidence is a function of the id, so that a lookup by id alone finds the same one)
+        peaks.append([(np.int64(rng.randint(0, 300)), np.int64(rng.randint(0, 300)), np.float64(0.3 + ((pid + i) * 37 % 64) / 90.0), pid + i)
+                      for i in range(n)])
+        pid += n
+    conns, special = [], []
+    for k in range(19):
+        pa, pb = peaks[ref.LIMB_FROM[k]], peaks[ref.LIMB_TO[k]]
+        if not pa or not pb or rng.rand() < 0.08:
+            special.append(k)
+            conns.append([])
+            continue
+        if kind in ('clean', 'big_ids', 'reused_ids', 'ragged'):
+            m = min(len(pa), len(pb))
+            ia, ib = np.arange(m), np.arange(m)
+            if k >= 17 and rng.rand() < 0.5:            # the redundant limbs tie ears to other people's shoulders
+                ib = rng.permutation(m)
+            keep = rng.rand(m) < 0.85
+            ia, ib = ia[keep], ib[keep]
+        elif kind == 'crossed':                         # a matching, but not along the people
+            m = min(len(pa), len(pb))
+            ia, ib = rng.permutation(len(pa))[:m], rng.permutation(len(pb))[:m]
+            keep = rng.rand(m) < 0.8
+            ia, ib = ia[keep], ib[keep]
+        else:                                           # 'shared': peaks used by several connections of a limb
+            m = int(rng.randint(1, 2 * people + 1))
+            ia, ib = rng.randint(0, len(pa), m), rng.randint(0, len(pb), m)
+        order = rng.permutation(len(ia))
+        rows = [[pa[ia[i]][3], pb[ib[i]][3], 0.2 + 0.8 * rng.rand(), pa[ia[i]][2], pb[ib[i]][2]] for i in order]
+        if rows:
+            conns.append(np.array(rows, np.float64))
+        else:
+            special.append(k)
+            conns.append([])
+    return peaks, conns, special
+
+
+@pytest.mark.parametrize('kind', ['clean', 'ragged', 'crossed', 'shared', 'big_ids', 'reused_ids'])
+def test_person_assembly_random_cases_against_the_oracle(kind, monkeypatch):
+    """multi_person_parse (utils/postprocess.py:163-237, predict.py:179-252) on drawn connection
+    sets: along the people (what the matching stage produces), with the redundant limbs crossed
+    (merges, two owners in conflict), matchings across the people, peaks shared by several
+    connections of a limb, ids beyond the lookup tables and ids that repeat from part to part.
+    Both variants; where predict.py would raise IndexError the library must as well."""
+    from poseestimation_amd import _ffi, postprocess
+    rng = np.random.RandomState({'clean': 11, 'ragged': 12, 'crossed': 13, 'shared': 14, 'big_ids': 15, 'reused_ids': 16}[kind])
+    raised = 0
+    for trial in range(40):
+        peaks, conns, special = _assembly_case(rng, kind)
+        for mode in ('P', 'D'):
+            monkeypatch.setattr(postprocess, '_MODE', _ffi.MODE_D if mode == 'D' else _ffi.MODE_P)
+            try:
+                want = ref.multi_person_parse(peaks, conns, special, mode)
+            except ref.TooManyOwners:
+                with pytest.raises(IndexError):
+                    postprocess.multi_person_parse(peaks, conns, special)
+                raised += 1
+                continue
+            got = postprocess.multi_person_parse(peaks, conns, special)
+            assert got.shape == want.shape, (kind, trial, mode)
+            np.testing.assert_array_equal(got, want, err_msg='%s trial %d mode %s' % (kind, trial, mode))
+    if kind == 'shared':
+        assert raised > 0
+
+
 @pytest.mark.parametrize('impl', [0, 1])
 @pytest.mark.parametrize('shape,dtype', [((40, 50), np.float64), ((40, 50), np.float32),
                                          ((5, 7), np.float64), ((368, 368), np.float64),

@@ -2,9 +2,9 @@
 """Where k_parse_pack's time goes (GPU).  Loads the stamped measurement build
 (make -C poseestimation_amd/csrc stamps; PD_LIBRARY points at it), decodes the headline batch
 a few times on one context and prints, per phase, the median over the workgroups of the last
-launch in microseconds from the first workgroup's start: the assembly wavefront, the three copy
-wavefronts, the barrier behind the write-through wait, the ticket, and the placement of all
-person rows by the last workgroup.
+launch in microseconds from the first workgroup's start: drawing the image number, the assembly
+wavefront, the three copy wavefronts, the look-back over the row counts of the images before,
+and the writing of the person rows.
 
 Usage: PD_LIBRARY=poseestimation_amd/libposedecode_stamps.so python tools/parse_pack_split.py [B H W]"""
 import ctypes as C
@@ -30,27 +30,35 @@ def main():
     for it in range(5):
         eng.enqueue_device(heat.data_ptr(), paf.data_ptr(), B, H // 8, W // 8)
         res = eng.fetch()
-    st = np.zeros((B, 8), np.int64)
+    st = np.zeros((B, 16), np.int64)
     assert L.pd_debug_pp_stamps(st.ctypes.data, B) == 0
     t0 = st[:, 0].min()
     us = (st - t0) / 100.0
-    names = ['start', 'assembly wavefront done', 'copy wavefront 1 done', 'copy wavefront 2 done', 'copy wavefront 3 done',
-             'past the wait + barrier', 'ticket drawn', 'last workgroup: rows placed, header written']
+    names = ['start', 'image number drawn', 'row count known and published (assembly done)', 'copy wavefront 1 done',
+             'copy wavefront 2 done', 'copy wavefront 3 done', 'look-back done', 'rows (last image: header) written']
     print('k_parse_pack, batch %d at %dx%d, %d persons: microseconds after the first workgroup starts'
           % (B, H, W, int(res.packed['person_count'].sum())))
+    names += ['connections staged', 'limbs applied']
     for q, n in enumerate(names):
+        if not n:
+            continue
         col = us[:, q]
-        if q == 7:
-            col = col[st[:, 7] >= t0]
         print('  %-48s min %6.2f  median %6.2f  max %6.2f' % (n, col.min(), np.median(col), col.max()))
-    own = (st[:, 1] - st[:, 0]) / 100.0
+    print('  limbs with connections %d, of them applied whole %d; connections per image: median %d, max %d'
+          % (st[:, 11].sum(), st[:, 10].sum(), np.median(st[:, 12]), st[:, 12].max()))
+    per = (st[:, 9] - st[:, 8]) / 100.0 / np.maximum(st[:, 11], 1)
+    print('  microseconds per limb with connections: median %.2f' % np.median(per))
+    cyc = st[:, 13] / np.maximum((st[:, 9] - st[:, 8]) / 100.0, 0.01)
+    print('  shader clock during the limbs: median %.0f cycles per microsecond; cycles per limb: median %.0f'
+          % (np.median(cyc), np.median(st[:, 13] / np.maximum(st[:, 11], 1))))
+    own = (st[:, 2] - st[:, 1]) / 100.0
     print('  assembly wavefront, own duration                 min %6.2f  median %6.2f  max %6.2f' % (own.min(), np.median(own), own.max()))
-    cp = (st[:, 2:5].max(axis=1) - st[:, 0]) / 100.0
+    cp = (st[:, 3:6].max(axis=1) - st[:, 1]) / 100.0
     print('  copy wavefronts, own duration (slowest of 3)     min %6.2f  median %6.2f  max %6.2f' % (cp.min(), np.median(cp), cp.max()))
-    last = st[:, 7] >= t0
-    if last.any():
-        b = int(np.nonzero(last)[0][0])
-        print('  last workgroup %d: placement %.2f us after its ticket' % (b, (st[b, 7] - st[b, 6]) / 100.0))
+    lb = (st[:, 6] - st[:, 2]) / 100.0
+    print('  look-back, wait after publishing                 min %6.2f  median %6.2f  max %6.2f' % (lb.min(), np.median(lb), lb.max()))
+    wr = (st[:, 7] - st[:, 6]) / 100.0
+    print('  barrier + writing the rows                       min %6.2f  median %6.2f  max %6.2f' % (wr.min(), np.median(wr), wr.max()))
 
 
 if __name__ == '__main__':
