@@ -173,12 +173,12 @@ struct WaveRec {
 
 // The wavefront's LDS.
 struct WaveShared {
-    int ids[PD_N_PARTS][64];
+    int ids[PD_N_PARTS + 1][64];  // (+ a spare row: where the lanes with nothing to write write)
     __attribute__((aligned(16))) double c_all[WAVE_CONNS * 4];  // staged connections; the table form's rows on hand-over
-    __attribute__((aligned(16))) WaveRec rec[64];  // person (lane) <- the connection that matches its near end, or opens it
-    short rec_b[64];                 // person <- the connection that matches its far end: (limb + 1) << 8 | connection
-    short who[WAVE_IDS];             // peak id -> the person that holds it (-1: nobody); exact while every limb went the fast way
-    short chk[WAVE_IDS];             // peak id -> connection of the current limb (written and read back by the same lanes)
+    __attribute__((aligned(16))) WaveRec rec[64 + 1];  // person (lane) <- the connection that matches its near end, or opens it
+    short rec_b[64 + 2];               // person <- the connection that matches its far end: (limb + 1) << 8 | connection
+    short who[WAVE_IDS + 4];           // peak id -> the person that holds it (-1: nobody); exact while every limb went the fast way
+    short chk[WAVE_IDS + 4];           // peak id -> connection of the current limb (written and read back by the same lanes)
     unsigned char part_of[WAVE_IDS]; // peak id -> the part it was seen as (0xff: not seen)
 };
 
@@ -335,13 +335,23 @@ __device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int 
     int n = st.n;
     int rc = 0;
     int by_id = st.by_id;
-    int dbg_fast = 0, dbg_limbs = 0;
-    const long long dbg_c0 = (long long)clock64();
     const int my_pa = pd_limb_from(min(lane, PD_N_LIMBS - 1)), my_pb = pd_limb_to(min(lane, PD_N_LIMBS - 1));
-    for (int k = k0; k < k1 && rc == 0; ++k) {
+    // the limbs of this call that have connections, and the connections of the first of them (one per lane)
+    unsigned todo = (unsigned)__ballot(mine && my_nc > 0);
+    int nx_ida = 0, nx_idb = 0;
+    double nx_score = 0.0, nx_ca = 0.0, nx_cb = 0.0;
+    if (todo != 0u) {
+        const int ci = min(at0 + __builtin_amdgcn_readlane(off, __builtin_ctz(todo)) + lane, WAVE_CONNS - 1);
+        nx_ida = c_ida[ci];
+        nx_idb = c_idb[ci];
+        nx_score = c_score[ci];
+        nx_ca = c_ca[ci];
+        nx_cb = c_cb[ci];
+    }
+    while (todo != 0u && rc == 0) {
+        const int k = __builtin_ctz(todo);
+        todo &= todo - 1u;
         const int nc = __builtin_amdgcn_readlane(my_nc, k), o = at0 + __builtin_amdgcn_readlane(off, k);
-        if (nc == 0) continue;
-        ++dbg_limbs;
         const int pa = __builtin_amdgcn_readlane(my_pa, k), pb = __builtin_amdgcn_readlane(my_pb, k);
         // Whole limb at once, one lane per connection and one per person.  When no two connections
         // of the limb share a peak (always so for connections that come from the matching
@@ -351,39 +361,43 @@ __device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int 
         // person, in connection order.  A connection finds its persons through the table
         // peak id -> person, which the fast way keeps exact; anything else (shared peaks, two
         // owners, merges, ids out of range) takes the loop, for this limb and all after it.
+        // Straight-line code: every lane makes every LDS access, the lanes with nothing to read
+        // or write at spare entries behind the tables; two round trips to LDS per limb, the
+        // connections of the next limb fetched during the first.
         if (by_id && nc <= 64) {
             const bool is_c = lane < nc;
-            const int ci = min(o + lane, WAVE_CONNS - 1);
-            const int ida = is_c ? c_ida[ci] : 0, idb = is_c ? c_idb[ci] : 0;
-            const double l_score = c_score[ci], l_ca = c_ca[ci], l_cb = c_cb[ci];
-            if (is_c) {
-                sh.chk[ida] = (short)lane;
-                sh.chk[idb] = (short)lane;
-            }
+            const int ida = nx_ida, idb = nx_idb;
+            const double l_score = nx_score, l_ca = nx_ca, l_cb = nx_cb;
+            const int ia = is_c ? ida : WAVE_IDS, ib = is_c ? idb : WAVE_IDS + 1;
+            sh.chk[ia] = (short)lane;
+            sh.chk[ib] = (short)lane;
             pd_wave_sync();
-            const int wa = is_c ? sh.who[ida] : -1, wb = is_c ? sh.who[idb] : -1;
-            const bool dup = is_c && (sh.chk[ida] != lane || sh.chk[idb] != lane);
+            const int wa_r = sh.who[ia], wb_r = sh.who[ib], ka = sh.chk[ia], kb = sh.chk[ib];
+            {
+                const int kn = todo != 0u ? __builtin_ctz(todo) : k;
+                const int ci = min(at0 + __builtin_amdgcn_readlane(off, kn) + lane, WAVE_CONNS - 1);
+                nx_ida = c_ida[ci];
+                nx_idb = c_idb[ci];
+                nx_score = c_score[ci];
+                nx_ca = c_ca[ci];
+                nx_cb = c_cb[ci];
+            }
+            const int wa = is_c ? wa_r : -1, wb = is_c ? wb_r : -1;
+            const bool dup = is_c && (ka != lane || kb != lane);
             const bool shared_conn = wa >= 0 && wb >= 0 && wa != wb;
             const bool unmatched = is_c && wa < 0 && wb < 0;
             const unsigned long long um = __ballot(unmatched);
             const int n_new = (a.mode == PD_MODE_D || k < 17) ? __builtin_popcountll(um) : 0;
             const int tag = (k + 1) << 8;
-            if (is_c) {
-                WaveRec r;
-                r.ab = (ida << 16) | idb;
-                if (wa >= 0) {
-                    r.meta = tag | lane;
-                    r.sc = l_cb + l_score;  // :210 / predict.py:205
-                    sh.rec[wa] = r;
-                }
-                if (wb >= 0) sh.rec_b[wb] = (short)(tag | lane);
-                const int slot = n + __builtin_popcountll(um & ((1ull << lane) - 1ull));
-                if (unmatched && n_new > 0 && slot < 64) {
-                    r.meta = tag | REC_NEW | lane;
-                    r.sc = (l_ca + l_cb) + l_score;  // utils/postprocess.py:196-205 / predict.py:228-244
-                    sh.rec[slot] = r;
-                }
-            }
+            const int slot = n + __builtin_popcountll(um & ((1ull << lane) - 1ull));
+            const bool opens = unmatched && n_new > 0 && slot < 64;
+            WaveRec r;
+            r.ab = (ida << 16) | idb;
+            r.meta = tag | lane | (wa >= 0 ? 0 : REC_NEW);
+            // extension: :210 / predict.py:205; new person: utils/postprocess.py:196-205 / predict.py:228-244
+            r.sc = wa >= 0 ? l_cb + l_score : (l_ca + l_cb) + l_score;
+            sh.rec[wa >= 0 ? wa : (opens ? slot : 64)] = r;
+            sh.rec_b[wb >= 0 ? wb : 64] = (short)(tag | lane);
             pd_wave_sync();
             const WaveRec mine_rec = sh.rec[lane];
             const int mine_b = sh.rec_b[lane];
@@ -397,24 +411,17 @@ __device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int 
                     rc = 1;
                     break;
                 }
-                const int tb = mine_rec.ab & 0xffff;
-                if (got_a && col_b != tb) {
-                    sh.ids[pb][lane] = tb;
-                    sh.who[tb] = (short)lane;
-                    my_cnt += 1;
-                    my_score += mine_rec.sc;
-                }
-                if (lane >= n && lane < n + n_new) {
-                    const int ta = mine_rec.ab >> 16;
-                    sh.ids[pa][lane] = ta;
-                    sh.ids[pb][lane] = tb;
-                    sh.who[ta] = (short)lane;
-                    sh.who[tb] = (short)lane;
-                    my_score = mine_rec.sc;
-                    my_cnt = 2;
-                }
+                const int tb = mine_rec.ab & 0xffff, ta = mine_rec.ab >> 16;
+                const bool is_new = lane >= n && lane < n + n_new;
+                const bool ext = got_a && col_b != tb;
+                sh.ids[is_new ? pa : PD_N_PARTS][lane] = ta;
+                sh.ids[ext || is_new ? pb : PD_N_PARTS][lane] = tb;
+                sh.who[is_new ? ta : WAVE_IDS + 2] = (short)lane;
+                sh.who[ext || is_new ? tb : WAVE_IDS + 2] = (short)lane;
+                my_cnt = is_new ? 2 : my_cnt + (ext ? 1 : 0);
+                const double grown = my_score + mine_rec.sc;
+                my_score = is_new ? mine_rec.sc : (ext ? grown : my_score);
                 n += n_new;
-                ++dbg_fast;
                 pd_wave_sync();
                 continue;
             }
@@ -509,10 +516,6 @@ __device__ __forceinline__ void wave_parse_limbs(const ParseArgs& a, int b, int 
     st.rc = rc;
     st.by_id = by_id;
     PP_STAMP(9, lane == 0);
-    PP_NOTE(10, lane == 0, dbg_fast);
-    PP_NOTE(11, lane == 0, dbg_limbs);
-    PP_NOTE(12, lane == 0, total);
-    PP_NOTE(13, lane == 0, (long long)clock64() - dbg_c0);
 }
 
 // Prune (:228-232 / predict.py:248-252), or hand the image over.  Returns the number of person

@@ -44,13 +44,8 @@ def main():
             continue
         col = us[:, q]
         print('  %-48s min %6.2f  median %6.2f  max %6.2f' % (n, col.min(), np.median(col), col.max()))
-    print('  limbs with connections %d, of them applied whole %d; connections per image: median %d, max %d'
-          % (st[:, 11].sum(), st[:, 10].sum(), np.median(st[:, 12]), st[:, 12].max()))
-    per = (st[:, 9] - st[:, 8]) / 100.0 / np.maximum(st[:, 11], 1)
-    print('  microseconds per limb with connections: median %.2f' % np.median(per))
-    cyc = st[:, 13] / np.maximum((st[:, 9] - st[:, 8]) / 100.0, 0.01)
-    print('  shader clock during the limbs: median %.0f cycles per microsecond; cycles per limb: median %.0f'
-          % (np.median(cyc), np.median(st[:, 13] / np.maximum(st[:, 11], 1))))
+    lim = (st[:, 9] - st[:, 8]) / 100.0
+    print('  applying the limbs                               min %6.2f  median %6.2f  max %6.2f' % (lim.min(), np.median(lim), lim.max()))
     own = (st[:, 2] - st[:, 1]) / 100.0
     print('  assembly wavefront, own duration                 min %6.2f  median %6.2f  max %6.2f' % (own.min(), np.median(own), own.max()))
     cp = (st[:, 3:6].max(axis=1) - st[:, 1]) / 100.0
