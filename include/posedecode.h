@@ -355,14 +355,17 @@ int pd_image_resize_pad(pd_ctx* ctx, const void* img, int img_dtype, int h, int 
                         int out_h, int out_w, int mem);
 
 /* visualize(), predict.py:256-307, as a per-pixel kernel.  img is (H, W, 3) uint8 on the
- * host.  circles[n][3] = (x, y, colour index): the filled radius-4 discs of predict.py:272
+ * host.  circles[n][3] = (x, y, colour index): the filled radius-4 circles of predict.py:269
  * in draw order; part_out receives cv2.addWeighted(img, 0.3, canvas, 0.7, 0)
  * (predict.py:277, part.jpg).  ellipses[m][6] = (cx, cy, a, b, angle in whole degrees,
- * colour index): the arguments predict.py:297 hands to cv2.ellipse2Poly for every (limb,
- * person), in draw order; each is filled and blended 0.4 / 0.6 into the canvas
- * (predict.py:298-299); final_out receives the canvas (final.jpg).  Colours are
- * predict.py:258-260's table.  Shapes are evaluated analytically per pixel; OpenCV
- * rasterises polygons, so outlines may differ by a pixel (no fixture exists to pin them).
+ * colour index): the arguments predict.py:298 hands to cv2.ellipse2Poly for every (limb,
+ * person), in draw order; each polygon is filled and blended 0.4 / 0.6 into the canvas
+ * (predict.py:299-300); final_out receives the canvas (final.jpg).  Colours are
+ * predict.py:258-260's table.  The shapes follow OpenCV's drawing algorithms as published
+ * (midpoint circle; vertices at whole degrees from a 7-decimal float32 sine table, rounded
+ * half to even; outline lines + 16.16 fixed-point scan fill), except that edges crossing
+ * the image border are not clipped first.  OpenCV is not available to check against and
+ * the reference holds no image of its output: parity of the pixels is not pinned.
  * Either output may be NULL. */
 int pd_render(pd_ctx* ctx, const uint8_t* img, int H, int W, int n_circles, const int32_t* circles,
               int n_ellipses, const int32_t* ellipses, uint8_t* part_out, uint8_t* final_out);

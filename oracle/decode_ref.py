@@ -398,7 +398,12 @@ def image_resize_pad(img, scale, stride=8, pad_value=128, out_dtype=None):
 
 
 # ----------------------------------------------------------------------------
-# visualize (predict.py:256-307)  -- UNPINNED: analytic shapes, not cv2's rasteriser
+# visualize (predict.py:256-307)  -- UNPINNED: cv2 is absent and the reference holds no image
+# of its output.  The shapes follow OpenCV's published drawing algorithms (imgproc/drawing.cpp)
+# as restated here from their description: the integer midpoint circle, ellipse2Poly's table of
+# sines of whole degrees with rounded vertices, fillConvexPoly's outline + fixed-point scan.
+# Lines are not clipped to the image first (cv2 moves the end points of an edge that crosses
+# the border onto it before it walks the edge), so shapes cut by the border may differ there.
 # ----------------------------------------------------------------------------
 
 COLORS = np.array([[255, 0, 0], [255, 85, 0], [255, 170, 0], [255, 255, 0], [170, 255, 0], [85, 255, 0], [0, 255, 0],
@@ -411,11 +416,174 @@ def _add_weighted(a, wa, b, wb):
     return np.clip(np.rint(a * np.float32(wa) + b * np.float32(wb)), 0, 255).astype(np.float32)
 
 
-def visualize(img, candidate, all_peaks, subset, limb_seq=None):
-    """predict.py:256-307 with per-pixel analytic shapes: discs dx^2 + dy^2 <= r^2 + r (r = 4)
-    for cv2.circle, the ellipse (centre, semi-axes, whole-degree angle) handed to
-    cv2.ellipse2Poly for the filled polygon.  Returns (part.jpg image, final.jpg image)."""
+def circle_rows(radius):
+    """cv2.circle(..., thickness=-1) with line type 8 and no shift: the integer midpoint walk;
+    half-width of the filled row at distance dy from the centre, for dy = 0 .. radius."""
+    half = [-1] * (radius + 1)
+    err, dx, dy, plus, minus = 0, radius, 0, 1, (radius << 1) - 1
+    while dx >= dy:
+        half[dy] = max(half[dy], dx)        # rows centre.y -+ dy span centre.x -+ dx
+        half[dx] = max(half[dx], dy)        # rows centre.y -+ dx span centre.x -+ dy
+        dy += 1
+        err += plus
+        plus += 2
+        if err > 0:
+            err -= minus
+            dx -= 1
+            minus -= 2
+    return half
+
+
+_SIN_TABLE = np.array([round(np.sin(np.deg2rad(d)), 7) for d in range(451)], np.float64).astype(np.float32)
+
+
+def ellipse2poly(center, axes, angle, arc_start=0, arc_end=360, delta=1):
+    """cv2.ellipse2Poly with integer centre and axes: vertices at every delta degrees from a
+    float32 table of sines of whole degrees (7 decimals), evaluated in double, rounded half to
+    even, consecutive duplicates dropped.  Returns a list of (x, y)."""
+    while angle < 0:
+        angle += 360
+    while angle > 360:
+        angle -= 360
+    if arc_start > arc_end:
+        arc_start, arc_end = arc_end, arc_start
+    while arc_start < 0:
+        arc_start += 360
+        arc_end += 360
+    while arc_end > 360:
+        arc_end -= 360
+        arc_start -= 360
+    if arc_end - arc_start > 360:
+        arc_start, arc_end = 0, 360
+    alpha = float(_SIN_TABLE[450 - angle])      # cosine
+    beta = float(_SIN_TABLE[angle])
+    pts, prev = [], None
+    i = arc_start
+    while i < arc_end + delta:
+        ang = min(i, arc_end)
+        if ang < 0:
+            ang += 360
+        x = float(axes[0]) * float(_SIN_TABLE[450 - ang])
+        y = float(axes[1]) * float(_SIN_TABLE[ang])
+        pt = (int(np.rint(center[0] + x * alpha - y * beta)), int(np.rint(center[1] + x * beta + y * alpha)))
+        if pt != prev:
+            pts.append(pt)
+            prev = pt
+        i += delta
+    if len(pts) == 1:
+        pts = [tuple(center), tuple(center)]
+    return pts
+
+
+def line_pixels(p1, p2):
+    """The 8-connected line cv2 draws between two pixels: walked from the left end, one step
+    along the longer axis per pixel, a step along the shorter one whenever the error term is
+    negative."""
+    (x1, y1), (x2, y2) = p1, p2
+    dx, dy = x2 - x1, y2 - y1
+    if dx < 0:
+        dx, dy, x1, y1 = -dx, -dy, x2, y2
+    sy = -1 if dy < 0 else 1
+    dy = abs(dy)
+    steep = dy > dx
+    major, minor = (dy, dx) if steep else (dx, dy)
+    err = major - 2 * minor
+    x, y, out = x1, y1, []
+    for _ in range(major + 1):
+        out.append((x, y))
+        neg = err < 0
+        err += -2 * minor + (2 * major if neg else 0)
+        if steep:
+            y += sy
+            x += 1 if neg else 0
+        else:
+            x += 1
+            y += sy if neg else 0
+    return out
+
+
+def _trunc_div(a, b):
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+def fill_convex_poly_mask(H, W, pts):
+    """cv2.fillConvexPoly(img, pts, colour) with line type 8 and no shift, as a boolean mask:
+    every edge drawn as a line, then rows ymin .. ymax filled between the two edge chains that
+    leave the top vertex, x kept in 16.16 fixed point and advanced by a rounded slope per row."""
+    XY_SHIFT = 16
+    XY_ONE = 1 << XY_SHIFT
+    mask = np.zeros((H, W), bool)
+    n = len(pts)
+    p0 = pts[-1]
+    for p in pts:
+        for (x, y) in line_pixels(p0, p):
+            if 0 <= x < W and 0 <= y < H:
+                mask[y, x] = True
+        p0 = p
+    xs_all = [p[0] for p in pts]
+    ys_all = [p[1] for p in pts]
+    ymin, ymax, xmin, xmax = min(ys_all), max(ys_all), min(xs_all), max(xs_all)
+    imin = ys_all.index(ymin)                      # the first vertex of the lowest y
+    if n < 3 or xmax < 0 or ymax < 0 or xmin >= W or ymin >= H:
+        return mask
+    ymax = min(ymax, H - 1)
+    edge = [dict(idx=imin, di=1, x=-XY_ONE, dx=0, ye=ymin), dict(idx=imin, di=n - 1, x=-XY_ONE, dx=0, ye=ymin)]
+    edges = n
+    y = ymin
+    while True:
+        for e in edge:
+            if y >= e['ye']:
+                idx0, di = e['idx'], e['di']
+                idx = idx0 + di
+                if idx >= n:
+                    idx -= n
+                while True:
+                    edges -= 1
+                    if edges < 0:
+                        break
+                    ty = pts[idx][1]
+                    if ty > y:
+                        xs, xe = pts[idx0][0] << XY_SHIFT, pts[idx][0] << XY_SHIFT
+                        e['ye'] = ty
+                        e['dx'] = _trunc_div((xe - xs) * 2 + (ty - y), 2 * (ty - y))
+                        e['x'] = xs
+                        e['idx'] = idx
+                        break
+                    idx0 = idx
+                    idx += di
+                    if idx >= n:
+                        idx -= n
+        if edges < 0:
+            break
+        if y >= 0:
+            left, right = (1, 0) if edge[0]['x'] > edge[1]['x'] else (0, 1)
+            xx1 = (edge[left]['x'] + (XY_ONE >> 1)) >> XY_SHIFT
+            xx2 = (edge[right]['x'] + (XY_ONE >> 1)) >> XY_SHIFT
+            if xx2 >= 0 and xx1 < W:
+                mask[y, max(xx1, 0):min(xx2, W - 1) + 1] = True
+        edge[0]['x'] += edge[0]['dx']
+        edge[1]['x'] += edge[1]['dx']
+        y += 1
+        if y > ymax:
+            break
+    return mask
+
+
+def limb_ellipse(candidate, index):
+    """predict.py:292-298: (centre, axes, angle) handed to cv2.ellipse2Poly for the limb between
+    the two candidates."""
     import math
+    Y = candidate[index.astype(int), 0]
+    X = candidate[index.astype(int), 1]
+    mX, mY = np.mean(X), np.mean(Y)
+    length = ((X[0] - X[1]) ** 2 + (Y[0] - Y[1]) ** 2) ** 0.5
+    angle = math.degrees(math.atan2(X[0] - X[1], Y[0] - Y[1]))
+    return (int(mY), int(mX)), (int(length / 2), 4), int(angle)
+
+
+def visualize(img, candidate, all_peaks, subset, limb_seq=None):
+    """predict.py:256-307.  Returns (part.jpg image, final.jpg image)."""
     if limb_seq is None:
         limb_seq = list(zip(LIMB_FROM, LIMB_TO))
     img = np.asarray(img, np.uint8)
@@ -423,10 +591,11 @@ def visualize(img, candidate, all_peaks, subset, limb_seq=None):
     yy, xx = np.mgrid[0:H, 0:W]
     base = img.astype(np.float32)
     canvas = base.copy()
+    half = np.array(circle_rows(4) + [-1])
     for i in range(18):
         for p in all_peaks[i]:
-            dx, dy = xx - int(p[0]), yy - int(p[1])                         # predict.py:272
-            canvas[dx * dx + dy * dy <= 4 * 4 + 4] = COLORS[i]
+            dx, dy = np.abs(xx - int(p[0])), np.minimum(np.abs(yy - int(p[1])), 5)      # predict.py:269
+            canvas[dx <= half[dy]] = COLORS[i]
     part = _add_weighted(base, 0.3, canvas, 0.7)                            # predict.py:277
     candidate = np.asarray(candidate, np.float64).reshape(-1, 4)
     for i in range(19):
@@ -436,20 +605,7 @@ def visualize(img, candidate, all_peaks, subset, limb_seq=None):
             index = np.asarray(subset[n])[np.array(limb_seq[i])]
             if -1 in index:
                 continue
-            Y = candidate[index.astype(int), 0]
-            X = candidate[index.astype(int), 1]
-            mX, mY = np.mean(X), np.mean(Y)
-            length = ((X[0] - X[1]) ** 2 + (Y[0] - Y[1]) ** 2) ** 0.5
-            angle = math.degrees(math.atan2(X[0] - X[1], Y[0] - Y[1]))
-            cx, cy, a, b, ang = int(mY), int(mX), int(length / 2), 4, int(angle)   # predict.py:297
-            a = np.float32(a if a >= 1 else 0.5)
-            b = np.float32(b)
-            co = np.float32(math.cos(ang * (math.pi / 180.0)))
-            si = np.float32(math.sin(ang * (math.pi / 180.0)))
-            dx = (xx - cx).astype(np.float32)
-            dy = (yy - cy).astype(np.float32)
-            u = (dx * co + dy * si) / a
-            v = (dy * co - dx * si) / b
-            inside = u * u + v * v <= np.float32(1.0)
-            canvas[inside] = _add_weighted(canvas[inside], 0.4, COLORS[i % 18][None, :], 0.6)   # predict.py:298-299
+            center, axes, ang = limb_ellipse(candidate, index)
+            inside = fill_convex_poly_mask(H, W, ellipse2poly(center, axes, ang))     # predict.py:298-299
+            canvas[inside] = _add_weighted(canvas[inside], 0.4, COLORS[i % 18][None, :], 0.6)   # predict.py:300
     return part.astype(np.uint8), canvas.astype(np.uint8)

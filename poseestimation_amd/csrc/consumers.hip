@@ -268,22 +268,37 @@ extern "C" int pd_image_resize_pad(pd_ctx* ctx, const void* img, int img_dtype, 
 
 // ---------------------------------------------------------------------------------
 // Skeleton rendering (predict.py:256-307): filled circles of radius 4 on the peaks, the blend
-// written as part.jpg, then one filled ellipse per (limb, person) blended into the canvas in
-// draw order.  Shapes are evaluated per pixel from their analytic form (a disc; an ellipse
-// with the integer centre, semi-axes and angle that predict.py:297 passes to ellipse2Poly);
-// OpenCV rasterises a 360-gon with fixed-point edges, so outlines can differ by a pixel.
+// written as part.jpg, then one filled polygon per (limb, person) blended into the canvas in
+// draw order.  The shapes follow OpenCV's drawing algorithms (imgproc/drawing.cpp) as published:
+// cv2.circle's integer midpoint walk; cv2.ellipse2Poly's vertices at whole degrees from a
+// float32 sine table of 7 decimals, rounded half to even; cv2.fillConvexPoly's outline lines plus
+// its scan in 16.16 fixed point.  OpenCV itself is not available to check against, and edges that
+// cross the image border are walked unclipped here (cv2 first moves their end points onto the
+// border).  The host rasterises every polygon into a bit mask over its bounding box; the kernel
+// looks pixels up in the masks.
 // ---------------------------------------------------------------------------------
 static __constant__ unsigned char c_colors[18][3] = {  // predict.py:258-260
     {255, 0, 0},   {255, 85, 0},  {255, 170, 0}, {255, 255, 0}, {170, 255, 0}, {85, 255, 0},
     {0, 255, 0},   {0, 255, 85},  {0, 255, 170}, {0, 255, 255}, {0, 170, 255}, {0, 85, 255},
     {0, 0, 255},   {85, 0, 255},  {170, 0, 255}, {255, 0, 255}, {255, 0, 170}, {255, 0, 85}};
 
+// half-width of the filled rows of cv2.circle(radius 4, thickness -1) at |dy| = 0 .. 4
+static __constant__ int c_disc4[5] = {4, 3, 3, 2, 0};
+
+struct ShapeMask {  // one polygon: bits of its bounding box (clipped to the image), row-major, 32 pixels a word
+    int x0, y0, x1, y1;
+    int words_per_row, colour;
+    unsigned int offset;  // first word in the mask array
+    int pad;
+};
+
 struct RenderArgs {
     const unsigned char* img;  // (H, W, 3)
     int H, W;
-    int n_circles, n_ellipses;
+    int n_circles, n_shapes;
     const int32_t* circles;    // [n][3]: x, y, colour index
-    const float* ellipses;     // [m][8]: cx, cy, a, b, cos, sin of the angle, colour index, 0
+    const ShapeMask* shapes;
+    const unsigned int* bits;
     unsigned char* part_out;   // (H, W, 3) or NULL
     unsigned char* final_out;  // (H, W, 3) or NULL
 };
@@ -302,8 +317,8 @@ k_render(RenderArgs a) {
     const float i0 = a.img[3 * i], i1 = a.img[3 * i + 1], i2 = a.img[3 * i + 2];
     float c0 = i0, c1 = i1, c2 = i2;
     for (int k = 0; k < a.n_circles; ++k) {
-        const int dx = x - a.circles[3 * k], dy = y - a.circles[3 * k + 1];
-        if (dx * dx + dy * dy <= 4 * 4 + 4) {  // raster disc of radius 4
+        const int dx = abs(x - a.circles[3 * k]), dy = abs(y - a.circles[3 * k + 1]);
+        if (dy <= 4 && dx <= c_disc4[dy]) {  // cv2.circle(canvas, peak, 4, colour, thickness=-1), predict.py:269
             const unsigned char* col = c_colors[a.circles[3 * k + 2] % 18];
             c0 = col[0];
             c1 = col[1];
@@ -316,12 +331,13 @@ k_render(RenderArgs a) {
         a.part_out[3 * i + 2] = (unsigned char)blend(i2, 0.3f, c2, 0.7f);
     }
     if (!a.final_out) return;
-    for (int k = 0; k < a.n_ellipses; ++k) {
-        const float* e = a.ellipses + 8 * k;
-        const float dx = (float)x - e[0], dy = (float)y - e[1];
-        const float u = (dx * e[4] + dy * e[5]) / e[2], v = (dy * e[4] - dx * e[5]) / e[3];
-        if (u * u + v * v <= 1.0f) {  // canvas = addWeighted(canvas, 0.4, cur_canvas, 0.6, 0), predict.py:299
-            const unsigned char* col = c_colors[(int)e[6] % 18];
+    for (int k = 0; k < a.n_shapes; ++k) {
+        const ShapeMask m = a.shapes[k];
+        if (x < m.x0 || x > m.x1 || y < m.y0 || y > m.y1) continue;
+        const int bx = x - m.x0;
+        const unsigned int word = a.bits[m.offset + (size_t)(y - m.y0) * m.words_per_row + (bx >> 5)];
+        if ((word >> (bx & 31)) & 1u) {  // canvas = addWeighted(canvas, 0.4, cur_canvas, 0.6, 0), predict.py:300
+            const unsigned char* col = c_colors[m.colour % 18];
             c0 = blend(c0, 0.4f, (float)col[0], 0.6f);
             c1 = blend(c1, 0.4f, (float)col[1], 0.6f);
             c2 = blend(c2, 0.4f, (float)col[2], 0.6f);
@@ -332,47 +348,203 @@ k_render(RenderArgs a) {
     a.final_out[3 * i + 2] = (unsigned char)c2;
 }
 
+// ---- the polygon of cv2.ellipse2Poly(centre, axes, angle, 0, 360, 1) and its filled mask (host) ----
+namespace {
+struct Pt {
+    long long x, y;
+};
+
+const float* sine_table() {  // sines of 0 .. 450 degrees to 7 decimals, as float32
+    static float tab[451];
+    static bool made = false;
+    if (!made) {
+        for (int d = 0; d <= 450; ++d) tab[d] = (float)(nearbyint(sin(d * (3.14159265358979323846 / 180.0)) * 1e7) / 1e7);
+        made = true;
+    }
+    return tab;
+}
+
+void ellipse_polygon(int cx, int cy, int ax, int ay, int angle, std::vector<Pt>& pts) {
+    const float* st = sine_table();
+    while (angle < 0) angle += 360;
+    while (angle > 360) angle -= 360;
+    const double alpha = st[450 - angle], beta = st[angle];
+    pts.clear();
+    for (int i = 0; i <= 360; ++i) {
+        const double x = (double)ax * st[450 - i], y = (double)ay * st[i];
+        Pt p;
+        p.x = (long long)nearbyint(cx + x * alpha - y * beta);  // (round half to even)
+        p.y = (long long)nearbyint(cy + x * beta + y * alpha);
+        if (pts.empty() || pts.back().x != p.x || pts.back().y != p.y) pts.push_back(p);
+    }
+    if (pts.size() == 1) pts.assign(2, Pt{cx, cy});
+}
+
+struct MaskWriter {
+    ShapeMask m;
+    std::vector<unsigned int>* bits;
+    void set(long long x, long long y) {
+        if (x < m.x0 || x > m.x1 || y < m.y0 || y > m.y1) return;
+        const long long bx = x - m.x0;
+        (*bits)[m.offset + (size_t)(y - m.y0) * m.words_per_row + (size_t)(bx >> 5)] |= 1u << (bx & 31);
+    }
+};
+
+// the 8-connected line between two pixels: from the left end, a step along the longer axis per
+// pixel, one along the shorter axis whenever the error term is negative
+void draw_line(MaskWriter& w, Pt p1, Pt p2) {
+    long long dx = p2.x - p1.x, dy = p2.y - p1.y;
+    if (dx < 0) {
+        dx = -dx;
+        dy = -dy;
+        p1 = p2;
+    }
+    const long long sy = dy < 0 ? -1 : 1;
+    if (dy < 0) dy = -dy;
+    const bool steep = dy > dx;
+    const long long major = steep ? dy : dx, minor = steep ? dx : dy;
+    long long err = major - 2 * minor, x = p1.x, y = p1.y;
+    for (long long i = 0; i <= major; ++i) {
+        w.set(x, y);
+        const bool neg = err < 0;
+        err += -2 * minor + (neg ? 2 * major : 0);
+        if (steep) {
+            y += sy;
+            if (neg) x += 1;
+        } else {
+            x += 1;
+            if (neg) y += sy;
+        }
+    }
+}
+
+void fill_polygon(MaskWriter& w, const std::vector<Pt>& v, int H, int W) {
+    const long long ONE = 1ll << 16;
+    const int n = (int)v.size();
+    Pt p0 = v[n - 1];
+    long long xmin = v[0].x, xmax = v[0].x, ymin = v[0].y, ymax = v[0].y;
+    int imin = 0;
+    for (int i = 0; i < n; ++i) {
+        if (v[i].y < ymin) {
+            ymin = v[i].y;
+            imin = i;
+        }
+        ymax = std::max(ymax, v[i].y);
+        xmax = std::max(xmax, v[i].x);
+        xmin = std::min(xmin, v[i].x);
+        draw_line(w, p0, v[i]);
+        p0 = v[i];
+    }
+    if (n < 3 || xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+    ymax = std::min<long long>(ymax, H - 1);
+    struct Edge {
+        int idx, di;
+        long long x, dx, ye;
+    } edge[2] = {{imin, 1, -ONE, 0, ymin}, {imin, n - 1, -ONE, 0, ymin}};
+    int edges = n;
+    long long y = ymin;
+    do {
+        for (Edge& e : edge) {
+            if (y < e.ye) continue;
+            int idx0 = e.idx, idx = idx0 + e.di;
+            if (idx >= n) idx -= n;
+            for (; edges-- > 0;) {
+                const long long ty = v[idx].y;
+                if (ty > y) {
+                    const long long xs = v[idx0].x * ONE, xe = v[idx].x * ONE;
+                    e.ye = ty;
+                    e.dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));  // (truncating division)
+                    e.x = xs;
+                    e.idx = idx;
+                    break;
+                }
+                idx0 = idx;
+                idx += e.di;
+                if (idx >= n) idx -= n;
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            const int left = edge[0].x > edge[1].x ? 1 : 0, right = 1 - left;
+            long long xx1 = (edge[left].x + (ONE >> 1)) >> 16, xx2 = (edge[right].x + (ONE >> 1)) >> 16;
+            if (xx2 >= 0 && xx1 < W) {
+                xx1 = std::max<long long>(xx1, 0);
+                xx2 = std::min<long long>(xx2, W - 1);
+                for (long long x = xx1; x <= xx2; ++x) w.set(x, y);
+            }
+        }
+        edge[0].x += edge[0].dx;
+        edge[1].x += edge[1].dx;
+    } while (++y <= ymax);
+}
+}  // namespace
+
 extern "C" int pd_render(pd_ctx* ctx, const uint8_t* img, int H, int W, int n_circles, const int32_t* circles,
                          int n_ellipses, const int32_t* ellipses, uint8_t* part_out, uint8_t* final_out) {
     PD_CHECK_CTX(ctx);
     PD_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
     if (!img || H < 1 || W < 1 || n_circles < 0 || n_ellipses < 0 || (n_circles && !circles) || (n_ellipses && !ellipses))
         PD_FAIL(ctx, PD_E_INVALID, "pd_render: bad arguments");
+    // (cx, cy, a, b, angle in whole degrees, colour) -> polygon -> bit mask over its bounding box
+    std::vector<ShapeMask> shapes((size_t)n_ellipses);
+    std::vector<unsigned int> bits;
+    std::vector<Pt> poly;
+    for (int i = 0; i < n_ellipses; ++i) {
+        const int32_t* e = ellipses + 6 * (size_t)i;
+        if (e[2] < 0 || e[3] < 0 || e[2] > (1 << 20) || e[3] > (1 << 20) || abs(e[0]) > (1 << 24) || abs(e[1]) > (1 << 24))
+            PD_FAIL(ctx, PD_E_INVALID, "pd_render: ellipse %d out of range", i);
+        ellipse_polygon(e[0], e[1], e[2], e[3], e[4], poly);
+        long long x0 = poly[0].x, x1 = x0, y0 = poly[0].y, y1 = y0;
+        for (const Pt& p : poly) {
+            x0 = std::min(x0, p.x);
+            x1 = std::max(x1, p.x);
+            y0 = std::min(y0, p.y);
+            y1 = std::max(y1, p.y);
+        }
+        MaskWriter w;
+        w.bits = &bits;
+        ShapeMask& m = w.m;
+        m.x0 = (int)std::max<long long>(x0, 0);
+        m.y0 = (int)std::max<long long>(y0, 0);
+        m.x1 = (int)std::min<long long>(x1, W - 1);
+        m.y1 = (int)std::min<long long>(y1, H - 1);
+        m.colour = e[5];
+        m.pad = 0;
+        m.offset = (unsigned int)bits.size();
+        m.words_per_row = m.x1 >= m.x0 ? (m.x1 - m.x0) / 32 + 1 : 0;
+        if (m.x1 >= m.x0 && m.y1 >= m.y0) {
+            bits.resize(bits.size() + (size_t)m.words_per_row * (m.y1 - m.y0 + 1), 0u);
+            fill_polygon(w, poly, H, W);
+        } else {
+            m.x1 = m.x0 - 1;  // nothing of it inside the image
+        }
+        shapes[(size_t)i] = m;
+    }
     const size_t img_bytes = (size_t)H * W * 3;
     const size_t off_part = align256(img_bytes), off_final = off_part + align256(img_bytes);
     const size_t off_circ = off_final + align256(img_bytes);
-    const size_t off_ell = off_circ + align256((size_t)n_circles * 3 * sizeof(int32_t));
-    int rc = aux_ensure(ctx, off_ell + align256((size_t)n_ellipses * 8 * sizeof(float)) + 256);
+    const size_t off_shape = off_circ + align256((size_t)n_circles * 3 * sizeof(int32_t));
+    const size_t off_bits = off_shape + align256(shapes.size() * sizeof(ShapeMask));
+    int rc = aux_ensure(ctx, off_bits + align256(bits.size() * sizeof(unsigned int)) + 256);
     if (rc != PD_OK) return rc;
     unsigned char* d = ctx->aux_dev;
-    // (cx, cy, a, b, angle in whole degrees, colour) -> centre, semi-axes, cosine and sine
-    std::vector<float> ell((size_t)n_ellipses * 8);
-    for (int i = 0; i < n_ellipses; ++i) {
-        const int32_t* e = ellipses + 6 * (size_t)i;
-        const double rad = (double)e[4] * (3.14159265358979323846 / 180.0);
-        float* o = ell.data() + 8 * (size_t)i;
-        o[0] = (float)e[0];
-        o[1] = (float)e[1];
-        o[2] = e[2] < 1 ? 0.5f : (float)e[2];  // an axis of 0 still covers the centre line
-        o[3] = e[3] < 1 ? 0.5f : (float)e[3];
-        o[4] = (float)cos(rad);
-        o[5] = (float)sin(rad);
-        o[6] = (float)e[5];
-        o[7] = 0.f;
-    }
     PD_HIP(ctx, hipMemcpyAsync(d, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (n_circles)
         PD_HIP(ctx, hipMemcpyAsync(d + off_circ, circles, (size_t)n_circles * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (n_ellipses)
-        PD_HIP(ctx, hipMemcpyAsync(d + off_ell, ell.data(), ell.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (n_ellipses) {
+        PD_HIP(ctx, hipMemcpyAsync(d + off_shape, shapes.data(), shapes.size() * sizeof(ShapeMask), hipMemcpyHostToDevice, ctx->stream));
+        if (!bits.empty())
+            PD_HIP(ctx, hipMemcpyAsync(d + off_bits, bits.data(), bits.size() * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->stream));
+    }
     RenderArgs a;
     a.img = d;
     a.H = H;
     a.W = W;
     a.n_circles = n_circles;
-    a.n_ellipses = n_ellipses;
+    a.n_shapes = n_ellipses;
     a.circles = (const int32_t*)(d + off_circ);
-    a.ellipses = (const float*)(d + off_ell);
+    a.shapes = (const ShapeMask*)(d + off_shape);
+    a.bits = (const unsigned int*)(d + off_bits);
     a.part_out = part_out ? d + off_part : nullptr;
     a.final_out = final_out ? d + off_final : nullptr;
     const size_t px = (size_t)H * W;
@@ -380,7 +552,7 @@ extern "C" int pd_render(pd_ctx* ctx, const uint8_t* img, int H, int W, int n_ci
     PD_HIP(ctx, hipGetLastError());
     if (part_out) PD_HIP(ctx, hipMemcpyAsync(part_out, d + off_part, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (final_out) PD_HIP(ctx, hipMemcpyAsync(final_out, d + off_final, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    // the host arrays above are pageable: the copies out of `ell` have completed by the time this returns
+    // the host arrays above are pageable: the copies out of them have completed by the time this returns
     PD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PD_OK;
 }

@@ -977,16 +977,14 @@ static void fill_pack_args(pd_ctx* ctx, PackArgs& a) {
 
 // Whether person assembly and packing of the current decode can share a launch: the library's
 // own result buffer (no capacity to check before anything is written), no skeleton buffer, the
-// wavefront form of the assembly with its hand-over inside the kernel, and small results (those
-// the packing stores to the host itself: one workgroup places all person rows, which takes
-// longer than a launch of its own once there are thousands of them).  PD_SEPARATE_PACK=1 in
+// wavefront form of the assembly with its hand-over inside the kernel.  PD_SEPARATE_PACK=1 in
 // the environment keeps the two launches (comparison runs).
 bool pd_parse_pack_fused(const pd_ctx* ctx) {
     static const bool separate = [] {
         const char* v = getenv("PD_SEPARATE_PACK");
         return v && *v && *v != '0';
     }();
-    return !separate && ctx->pack_direct && ctx->pack_sync && ctx->impl != PD_IMPL_SIMPLE && !ctx->dbg_found && !ctx->skel_dst &&
+    return !separate && ctx->pack_sync && ctx->impl != PD_IMPL_SIMPLE && !ctx->dbg_found && !ctx->skel_dst &&
            ctx->host_results && ctx->res_user_cap == 0 && ctx->have_peaks && ctx->have_conns &&
            (size_t)ctx->cfg.max_persons * 20 <= (size_t)WAVE_CONNS * 4 && ctx->cfg.max_persons < PP_NOT_OK;
 }

@@ -145,9 +145,10 @@ def test_detect_end_to_end_with_a_stand_in_network():
     gio.assert_persons_equal(subset, want_subset, 1e-5)
 
 
-def test_render_matches_the_analytic_restatement():
-    """predict.py:256-307: the part image (discs only, integer tests) bit for bit; the final
-    image up to outline pixels whose float32 ellipse test sits on the boundary."""
+def test_render_matches_the_restated_rasteriser():
+    """predict.py:256-307 against the oracle's restatement of cv2.circle / ellipse2Poly /
+    fillConvexPoly / addWeighted: both images bit for bit, also with limbs that leave the image
+    on every side and with limbs of no length."""
     from poseestimation_amd import predict_decode as pdec, synth
     H, W = 184, 248
     heat, paf = synth.scene(H, W, 3, 41, paf_order='xy')
@@ -159,9 +160,25 @@ def test_render_matches_the_analytic_restatement():
     part, final = pdec.visualize(img, cand, peaks, subset, write=False)
     want_part, want_final = ref.visualize(img, cand, peaks, subset)
     np.testing.assert_array_equal(part, want_part)
-    differing = np.any(final != want_final, axis=2).mean()
-    assert differing < 2e-3, differing
+    np.testing.assert_array_equal(final, want_final)
     assert np.any(final != img) and np.any(part != img)
+    # made-up skeletons: every angle, limbs across the borders, coincident ends
+    rng = np.random.RandomState(2)
+    n_cand = 18 * 6
+    cand2 = np.zeros((n_cand, 4))
+    cand2[:, 0] = rng.randint(-30, W + 30, n_cand)
+    cand2[:, 1] = rng.randint(-30, H + 30, n_cand)
+    cand2[:6, :2] = cand2[6:12, :2]                      # parts 0 and 1 of every person coincide
+    cand2[:, 3] = np.arange(n_cand)
+    peaks2 = [[(int(cand2[p * 6 + j, 0]), int(cand2[p * 6 + j, 1]), 0.5, p * 6 + j) for j in range(6)] for p in range(18)]
+    subset2 = -np.ones((6, 20))
+    for j in range(6):
+        subset2[j, :18] = np.arange(18) * 6 + j
+    subset2[2, 4] = -1
+    part2, final2 = pdec.visualize(img, cand2, peaks2, subset2, write=False)
+    want_part2, want_final2 = ref.visualize(img, cand2, peaks2, subset2)
+    np.testing.assert_array_equal(part2, want_part2)
+    np.testing.assert_array_equal(final2, want_final2)
     # nothing to draw: the image comes back unchanged
     p0, f0 = pdec.visualize(img, np.zeros((0, 4)), [[] for _ in range(18)], np.zeros((0, 20)), write=False)
     np.testing.assert_array_equal(f0, img)
