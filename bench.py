@@ -159,6 +159,9 @@ def main():
         have_q = 4
     if args.hw_queues > have_q:
         os.environ['GPU_MAX_HW_QUEUES'] = str(args.hw_queues)
+    # (sharing device memory between the ranks' processes needs dmabuf handles on this stack; the launcher's environment
+    # normally carries this already)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     all_cores = None
     # (not under a profiler: its preloaded library may have started the GPU runtime already,
     # and a process in that state is not forked)
