@@ -250,3 +250,61 @@ def test_sharing_context_waits_for_work_queued_outside_decode_batch():
         assert np.array_equal(got[key], want_big[key]), key
     b.close()
     plain.close()
+
+
+def test_person_rows_keep_their_places_through_changing_batches_and_busy_streams():
+    """Assembly and packing in one launch place each image's person rows by a look-back over the
+    row counts of the images before it, through words that carry the launch's tag.  Batches of
+    changing size through one context (fewer images, then more again: the words of the images
+    beyond a batch must not be taken for this launch's), replayed sequences included, and four
+    contexts on streams of their own decoding at once, many times over: the packed bytes must be
+    those of a context that keeps assembly and packing apart."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from poseestimation_amd import synth
+    from poseestimation_amd.predict_decode import DecodeEngine
+    H = W = 184
+    heat, paf = synth.batch(24, H, W, (0, 6), seed0=900, paf_order='xy')
+    heat[5] = 0          # an image without anybody in the middle of the batch
+    d_heat, d_paf = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    # the reference results come from a process with PD_SEPARATE_PACK=1 (the switch is read once per process)
+    code = ('import numpy as np, sys\n'
+            'from poseestimation_amd import synth\n'
+            'from poseestimation_amd.predict_decode import DecodeEngine\n'
+            'heat, paf = synth.batch(24, %d, %d, (0, 6), seed0=900, paf_order="xy")\n'
+            'heat[5] = 0\n'
+            'eng = DecodeEngine(max_batch=24, max_h=%d, max_w=%d, mode="D")\n'
+            'out = {}\n'
+            'for B in (24, 3, 1, 17, 24):\n'
+            '    r = eng.decode_batch(heat[:B], paf[:B]).packed\n'
+            '    for k in %r:\n'
+            '        out["%%d_%%s" %% (B, k)] = r[k]\n'
+            'np.savez(sys.argv[1], **out)\n' % (H, W, H, W, KEYS))
+    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'pd_separate_pack_%d.npz' % os.getpid())
+    env = dict(os.environ, PD_SEPARATE_PACK='1', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    subprocess.run([sys.executable, '-c', code, path], check=True, env=env, timeout=240)
+    want = dict(np.load(path))
+    os.remove(path)
+    assert want['24_person_count'].sum() > 20 and want['24_person_count'][5] == 0
+
+    def check(res, B, where):
+        for k in KEYS:
+            assert np.array_equal(res[k], want['%d_%s' % (B, k)]), (where, B, k)
+
+    eng = DecodeEngine(max_batch=24, max_h=H, max_w=W, mode='D')
+    for rep in range(3):                        # (the third identical call replays a recorded sequence)
+        for B in (24, 3, 1, 17, 24, 24, 24):
+            eng.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, H // 8, W // 8)
+            check(eng.fetch().packed, B, 'one context, pass %d' % rep)
+    # four contexts at once
+    engs = [eng] + [DecodeEngine(max_batch=24, max_h=H, max_w=W, mode='D') for _ in range(3)]
+    for it in range(40):
+        sizes = [(24, 17, 3, 24)[(it + j) % 4] for j in range(4)]
+        for e, B in zip(engs, sizes):
+            e.enqueue_device(d_heat.data_ptr(), d_paf.data_ptr(), B, H // 8, W // 8)
+        for e, B in zip(engs, sizes):
+            check(e.fetch().packed, B, 'four contexts, round %d' % it)
+    for e in engs:
+        e.close()
