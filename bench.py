@@ -229,9 +229,10 @@ def other_workloads(env, out):
     args = env['args']
     failed = False
     legs = {}
-    # the headline batch in mode P.  (First: the round pipeline of the stream leg takes streams from torch's pool, whose
-    # 32 streams are created at that moment; contexts created after that were seen to share hardware queues two by two --
-    # the same batch then runs at 0.74 M images/s instead of 1.34 M.)
+    # the headline batch in mode P.  (First: the round pipeline of the stream leg orders its copies behind the decodes
+    # with stream waits, and once contexts whose streams were waited for are destroyed, contexts made later in the
+    # process were seen to decode at half the rate -- the same batch at 0.74 M images/s instead of 1.34 M;
+    # tools/stream_wait_probe.py.)
     a = copy.copy(args)
     a.mode, a.steps, a.warmup, a.no_extras, a.cpu_images = 'P', 200, 60, True, 6
     try:
