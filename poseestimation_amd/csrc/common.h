@@ -414,13 +414,15 @@ void pd_up8_fill(Up8* u);
 int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
                            const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W,
                            float* absmax);
-// max over the wavefront of a non-negative float, rounded up one ulp, folded into *dst (as bits)
+// max over the wavefront of a non-negative float, rounded up one ulp (an infinity stays one), folded
+// into *dst (as bits)
 __device__ __forceinline__ void pd_wave_absmax(float m, float* dst) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    const unsigned int bits = m <= 3.4028235e38f ? __float_as_uint(m) + 1u : 0x7f800000u;
     // the running maximum only grows: a stale read costs one needless atomic at most
-    if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) + 1u > __atomic_load_n((unsigned int*)dst, __ATOMIC_RELAXED))
-        atomicMax((unsigned int*)dst, __float_as_uint(m) + 1u);
+    if ((threadIdx.x & 63) == 0 && m > 0.f && bits > __atomic_load_n((unsigned int*)dst, __ATOMIC_RELAXED))
+        atomicMax((unsigned int*)dst, bits);
 }
 MapSource pd_heat_source(const pd_ctx* ctx);
 MapSource pd_paf_source(const pd_ctx* ctx);

@@ -405,7 +405,7 @@ k_ms_cells64(MsArgs a) {
                 const int i = i0 + 256 * k + tid;
                 if (i < hs * ws) {
                     A[i] = fabsf(t[k]);
-                    mx = fmaxf(mx, fabsf(t[k]));
+                    mx = absmax_step(mx, t[k]);
                 }
             }
         }
@@ -423,15 +423,22 @@ k_ms_cells64(MsArgs a) {
     if (lane == 0) s_red[wv] = mx;
     __syncthreads();
     float thr_lo = 0.f, e2 = 0.f;
+    int finite = 1;
     if (lane == 0) {
-        filter_slack(a.thr, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), &thr_lo, &e2, MSF_EPS_SHIFT);
-        if (wv == 0) a.slack[plane] = make_float2(thr_lo, e2);
+        const float pm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        filter_slack(a.thr, pm, &thr_lo, &e2, MSF_EPS_SHIFT);
+        finite = absmax_finite(pm);
+        if (wv == 0) {
+            a.slack[plane] = make_float2(thr_lo, e2);
+            if (!finite) atomicOr(a.cand_count + plane, KF_OVERFLOW);  // the exact kernel takes this plane
+        }
     }
     thr_lo = __shfl(thr_lo, 0);
+    finite = __shfl(finite, 0);
     unsigned mask = 0u;
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-        if (act && wv + 4 * k < hc && U[k] * 1.00001f >= thr_lo) mask |= 1u << k;
+        if (act && finite && wv + 4 * k < hc && U[k] * 1.00001f >= thr_lo) mask |= 1u << k;
     const int mine = __builtin_popcount(mask);
     int incl = mine;
 #pragma unroll
@@ -481,7 +488,7 @@ k_ms_cells(MsArgs a) {
         for (int i = tid; i < hs * ws; i += 256) {
             const float v = fabsf(src[i]);
             A[i] = v;
-            mx = fmaxf(mx, v);
+            mx = absmax_step(mx, v);
         }
         __syncthreads();
         for (int e = tid; e < hs * wc; e += 256) {
@@ -524,14 +531,21 @@ k_ms_cells(MsArgs a) {
     if (lane == 0) s_red[wv] = mx;
     __syncthreads();
     float thr_lo = 0.f, e2 = 0.f;
+    int finite = 1;
     if (lane == 0) {
-        filter_slack(a.thr, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), &thr_lo, &e2, MSF_EPS_SHIFT);
-        if (wv == 0) a.slack[plane] = make_float2(thr_lo, e2);
+        const float pm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        filter_slack(a.thr, pm, &thr_lo, &e2, MSF_EPS_SHIFT);
+        finite = absmax_finite(pm);
+        if (wv == 0) {
+            a.slack[plane] = make_float2(thr_lo, e2);
+            if (!finite) atomicOr(a.cand_count + plane, KF_OVERFLOW);  // the exact kernel takes this plane
+        }
     }
     thr_lo = __shfl(thr_lo, 0);
+    finite = __shfl(finite, 0);
     // the list: a reservation per workgroup in the segment of the plane, entries in cell order per thread
     int mine = 0;
-    for (int e = tid; e < n_cells; e += 256) mine += U[e] * 1.00001f >= thr_lo;
+    for (int e = tid; e < n_cells; e += 256) mine += finite && U[e] * 1.00001f >= thr_lo;
     int incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -550,7 +564,7 @@ k_ms_cells(MsArgs a) {
     for (int q = 0; q < wv; ++q) at += s_cnt[q];
     int32_t* segment = a.cells + (size_t)seg * a.seg_cap;
     for (int e = tid; e < n_cells; e += 256)
-        if (U[e] * 1.00001f >= thr_lo) {
+        if (finite && U[e] * 1.00001f >= thr_lo) {
             const int cy = e / wc, cx = e - cy * wc;
             segment[at++] = (plane << 14) | (cy << 7) | cx;
         }

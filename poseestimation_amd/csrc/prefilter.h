@@ -26,6 +26,17 @@ __device__ __forceinline__ void filter_slack(double thr, float absmax, float* th
     *e2 = nextafterf((float)(2.0 * eps), INFINITY);
 }
 
+// One step of max |v| over a plane that does not lose what the tolerance cannot cover: a NaN or an
+// infinity makes the maximum +inf.  The float32 filter multiplies sources outside an output's
+// support by zero weights, which a non-finite value turns into NaN where the reference, which never
+// touches that source, has a finite value; planes with such values are left to the exact kernel
+// (their candidate count gets KF_OVERFLOW and no cell of theirs is listed).
+__device__ __forceinline__ float absmax_step(float m, float v) {
+    const float a = fabsf(v);
+    return a <= m ? m : (a == a ? a : INFINITY);   // (a <= m is false for a NaN)
+}
+__device__ __forceinline__ bool absmax_finite(float m) { return m <= 3.4028235e38f; }
+
 // Exclusive prefix of the segment counts (each clipped to the segment capacity) into
 // pref[0 .. KF_NSEG]; call with all threads, ends with a barrier.
 __device__ __forceinline__ void segment_prefix(const int32_t* counts, int seg_cap, int* pref, int tid) {

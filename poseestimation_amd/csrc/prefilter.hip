@@ -260,6 +260,7 @@ struct CellArgs {
     int seg_cap;
     int32_t* n_reg;       // [KF_NSEG]
     int32_t* n_edge;      // [KF_NSEG]
+    int32_t* cand_count;  // [B * 18]: KF_OVERFLOW for a plane with non-finite values (the exact kernel takes it)
 };
 
 // One workgroup per (part, image) plane.  Once the plane is in LDS every thread owns a cell
@@ -310,7 +311,7 @@ k_cells(CellArgs a) {
             const int i = i0 + k * NT + tid;
             if (i < h * w) {
                 A[i] = fabsf(t[k]);
-                m = fmaxf(m, fabsf(t[k]));
+                m = absmax_step(m, t[k]);
                 if (copy) copy[i] = t[k];
             }
         }
@@ -323,16 +324,22 @@ k_cells(CellArgs a) {
     // the rounding of the float32 evaluation.  A few dozen float64 instructions, one lane per
     // wavefront does them.
     float thr_lo = 0.f;
+    int finite = 1;
     if (lane == 0) {
         float pm = 0.f, e2;
         for (int q = 0; q < n_waves; ++q) pm = fmaxf(pm, s_red[q]);
         filter_slack(a.thr, pm, &thr_lo, &e2);
-        if (wv == 0) a.slack[plane] = make_float2(thr_lo, e2);
+        finite = absmax_finite(pm);
+        if (wv == 0) {
+            a.slack[plane] = make_float2(thr_lo, e2);
+            if (!finite) atomicOr(a.cand_count + plane, KF_OVERFLOW);
+        }
     }
     thr_lo = __shfl(thr_lo, 0);
+    finite = __shfl(finite, 0);
     // ---- the bound U of every cell of the thread's band
     unsigned m_reg = 0u, m_edge = 0u;
-    if (yb > ya) {
+    if (yb > ya && finite) {
         float kx[7];
         int cx[7];
 #pragma unroll
@@ -834,7 +841,7 @@ k_cells_filter(CellsFilterArgs args) {
                 const int i = i0 + k * 256 + tid;
                 if (i < h * w) {
                     P[i] = t[k];
-                    m = fmaxf(m, fabsf(t[k]));
+                    m = absmax_step(m, t[k]);
                     copy[i] = t[k];
                 }
             }
@@ -852,7 +859,7 @@ k_cells_filter(CellsFilterArgs args) {
                 const int i = i0 + k * 256 + tid;
                 if (i < h * w) {
                     P[i] = t[k];
-                    m = fmaxf(m, fabsf(t[k]));
+                    m = absmax_step(m, t[k]);
                 }
             }
         }
@@ -862,12 +869,19 @@ k_cells_filter(CellsFilterArgs args) {
     if (lane == 0) s_red[wv] = m;
     __syncthreads();
     float thr_lo = 0.f, e2 = 0.f;
-    if (lane == 0) filter_slack(a.thr, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), &thr_lo, &e2);
+    int finite = 1;
+    if (lane == 0) {
+        const float pm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        filter_slack(a.thr, pm, &thr_lo, &e2);
+        finite = absmax_finite(pm);
+        if (wv == 0 && !finite) atomicOr(args.f.cand_count + plane, KF_OVERFLOW);  // the exact kernel takes this plane
+    }
     thr_lo = __shfl(thr_lo, 0);
     e2 = __shfl(e2, 0);
+    finite = __shfl(finite, 0);
     // ---- the bound U of every cell of the thread's band (as in k_cells)
     unsigned m_reg = 0u, m_edge = 0u;
-    if (yb > ya) {
+    if (yb > ya && finite) {
         float kx[7];
         int cx[7];
 #pragma unroll
@@ -1165,7 +1179,7 @@ k_tile_filter(CellsFilterArgs args, int tiles_x, int tiles_per_image, int n_tile
         const int part = tid / 14, sub = tid - part * 14;
         const float* pl = sh.P + part * TF_PLANE;
         float m = 0.f;
-        for (int i = sub; i < TF_SRC * TF_SRC; i += 14) m = fmaxf(m, fabsf(pl[(i >> 4) * TF_PSTR + (i & 15)]));
+        for (int i = sub; i < TF_SRC * TF_SRC; i += 14) m = absmax_step(m, pl[(i >> 4) * TF_PSTR + (i & 15)]);
         atomicMax(&sh.absmax[part], __float_as_uint(m));
     }
     // ---- row sums of the bound: part, source row cy0-3+q (q < 14), cell column (a thread's cell
@@ -1188,7 +1202,12 @@ k_tile_filter(CellsFilterArgs args, int tiles_x, int tiles_per_image, int n_tile
     __syncthreads();
     if (tid < PD_N_PARTS) {
         float tl, ee;
-        filter_slack(a.thr, __uint_as_float(sh.absmax[tid]), &tl, &ee);
+        const float pm = __uint_as_float(sh.absmax[tid]);
+        filter_slack(a.thr, pm, &tl, &ee);
+        if (!absmax_finite(pm)) {  // non-finite values in this part's share of the tile: the exact kernel takes the plane
+            atomicOr(args.f.cand_count + b * PD_N_PARTS + tid, KF_OVERFLOW);
+            tl = INFINITY;         // (and none of its cells in this tile is listed)
+        }
         sh.thr_lo[tid] = tl;
         sh.e2[tid] = ee;
     }
@@ -1211,7 +1230,8 @@ k_tile_filter(CellsFilterArgs args, int tiles_x, int tiles_per_image, int n_tile
                 u = fmaf(kb.x, col[4 * TF_TC], u);
                 u = fmaf(kb.y, col[5 * TF_TC], u);
                 u = fmaf(kb.z, col[6 * TF_TC], u);
-                if (u * 1.00001f >= sh.thr_lo[part]) {  // the factor covers the rounding of the chains on both sides
+                const float tl = sh.thr_lo[part];
+                if (u * 1.00001f >= tl && tl < INFINITY) {  // the factor covers the rounding of the chains on both sides
                     if (reg)
                         sh.list[atomicAdd(&sh.n_reg, 1)] = (unsigned short)e;
                     else
@@ -1479,6 +1499,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     c.seg_cap = (int)seg_cap;
     c.n_reg = counters + KF_NSEG;
     c.n_edge = counters + 2 * KF_NSEG;
+    c.cand_count = ctx->cand_count;
 
     CellFilterArgs f;
     f.lo = ctx->heat_planar;
