@@ -9,7 +9,7 @@ With --multiscale: two to four random test scales between 0.4 and 2.2 with non-z
 network outputs per scale, through pd_decode_multiscale (no stored maps) against the oracle's resize + average +
 decode (predict.py:49-254).
 
-Usage (on a GPU box): python tools/fuzz_decode.py [--cases 200] [--seed 0] [--batch 4] [--multiscale]
+Usage (on a GPU box): python tools/fuzz_decode.py [--cases 200] [--seed 0] [--batch 4] [--multiscale | --large]
 Prints one line per mismatch and a summary; exit status 1 if anything differed."""
 import argparse
 import os
@@ -31,7 +31,13 @@ def smooth(rng, shape, passes):
     return a / np.float32(np.abs(a).max() + 1e-6)
 
 
-def make_case(rng):
+def make_case(rng, large=False):
+    if large:   # maps of more than 4096 pixels: the two-kernel peak stage, the layout copies, the pair pre-test
+        h, w = int(rng.integers(60, 92)), int(rng.integers(70, 92))
+        H, W = 8 * h - int(rng.integers(0, 8)), 8 * w - int(rng.integers(0, 8))
+        heat = smooth(rng, (h, w, 19), int(rng.integers(12, 40))) * np.float32(rng.choice([0.6, 1.0]))
+        paf = smooth(rng, (h, w, 38), int(rng.integers(4, 12))) * np.float32(0.5)
+        return heat, paf, (H, W)
     h, w = int(rng.integers(4, 18)), int(rng.integers(4, 18))
     crop = rng.random() < 0.5
     H = 8 * h - (int(rng.integers(0, 8)) if crop else 0)
@@ -119,6 +125,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--multiscale', action='store_true')
+    ap.add_argument('--large', action='store_true', help='maps of 60..91 x 70..91 network pixels')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
     if args.multiscale:
@@ -128,7 +135,7 @@ def main():
     totals = [0, 0, 0]
     for case in range(args.cases):
         rng = np.random.default_rng(args.seed * 100003 + case)
-        heat0, paf0, (H, W) = make_case(rng)
+        heat0, paf0, (H, W) = make_case(rng, args.large)
         mode = 'DP'[case % 2]
         t1, t2 = float(rng.choice([0.1, 0.05, 0.3])), float(rng.choice([0.05, 0.02, 0.2]))
         # the images of a batch share the geometry: the first is the case, the others are its flips and negation
@@ -136,7 +143,7 @@ def main():
                 (-heat0, -paf0)][:args.batch]
         want = [oracle(hm, pm, H, W, mode, t1, t2) for hm, pm in imgs]
         eng = pdec.DecodeEngine(max_batch=len(imgs), max_h=8 * heat0.shape[0], max_w=8 * heat0.shape[1], mode=mode,
-                                max_peaks_per_part=256, max_persons=204, max_pairs_per_image=400000)
+                                max_peaks_per_part=512 if args.large else 256, max_persons=1024 if args.large else 204, max_pairs_per_image=2000000 if args.large else 400000)
         tag = 'case %d (seed %d) mode %s %dx%d -> %dx%d thr %.2f/%.2f' % (case, args.seed, mode, heat0.shape[0], heat0.shape[1],
                                                                          H, W, t1, t2)
         expect_index = [b for b, wv in enumerate(want) if wv[3] is IndexError]
