@@ -9,7 +9,7 @@ With --multiscale: two to four random test scales between 0.4 and 2.2 with non-z
 network outputs per scale, through pd_decode_multiscale (no stored maps) against the oracle's resize + average +
 decode (predict.py:49-254).
 
-Usage (on a GPU box): python tools/fuzz_decode.py [--cases 200] [--seed 0] [--batch 4] [--multiscale | --large]
+Usage (on a GPU box): python tools/fuzz_decode.py [--cases 200] [--seed 0] [--batch 4] [--multiscale | --large | --images]
 Prints one line per mismatch and a summary; exit status 1 if anything differed."""
 import argparse
 import os
@@ -119,17 +119,49 @@ def multiscale_cases(args):
     return 1 if bad else 0
 
 
+def image_cases(args):
+    """pd_image_resize_pad (predict.py:56-57) against the restatement: random sizes, scales 0.2..3, uint8 (noise,
+    black / white blocks whose cubic overshoot saturates, constant) and float32."""
+    bad = n = 0
+    for case in range(args.cases):
+        rng = np.random.default_rng(args.seed * 100003 + 1000 + case)
+        ih, iw = int(rng.integers(9, 300)), int(rng.integers(9, 300))
+        scale = float(rng.uniform(0.2, 3.0))
+        if case % 2 == 0:
+            kind = (case // 2) % 3
+            if kind == 0:
+                img = rng.integers(0, 256, (ih, iw, 3)).astype(np.uint8)
+            elif kind == 1:
+                img = (rng.integers(0, 2, (ih // 3 + 1, iw // 3 + 1, 3)) * 255).astype(np.uint8).repeat(3, 0).repeat(3, 1)[:ih, :iw]
+            else:
+                img = np.full((ih, iw, 3), int(rng.integers(0, 256)), np.uint8)
+        else:
+            img = (rng.random((ih, iw, 3)) * 255).astype(np.float32)
+        img = np.ascontiguousarray(img)
+        want, wpad = ref.image_resize_pad(img, scale, 8, 128)
+        got, gpad = pdec.resize_pad(img, scale)
+        n += 1
+        if got.dtype != want.dtype or got.shape != want.shape or tuple(gpad) != tuple(wpad) or not np.array_equal(got, want):
+            bad += 1
+            print('image case %d (seed %d): %dx%d %s scale %.4f differs' % (case, args.seed, ih, iw, img.dtype, scale))
+    print('%d image resize cases: %d mismatches' % (n, bad))
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--multiscale', action='store_true')
+    ap.add_argument('--images', action='store_true', help='the image resize + pad in front of the network instead of the decode')
     ap.add_argument('--large', action='store_true', help='maps of 60..91 x 70..91 network pixels')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
     if args.multiscale:
         return multiscale_cases(args)
+    if args.images:
+        return image_cases(args)
     bad = 0
     index_errors = 0
     totals = [0, 0, 0]
