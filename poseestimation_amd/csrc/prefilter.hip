@@ -683,7 +683,7 @@ struct CellsFilterArgs {
 // The cells of one kind in the workgroup's LDS list `list` (n of them): six per wavefront pass,
 // ten lanes per cell, windows from the plane `P` ([h][w], signed values).
 template <bool REG>
-__device__ __forceinline__ void filter_cells_lds(const CellFilterArgs& a, PlaneFilterShared& sh, const float* P, const int* list,
+__device__ __forceinline__ void filter_cells_lds(const CellFilterArgs& a, PlaneFilterShared& sh, const float* P, const unsigned short* list,
                                                  int n, int list_step, int plane, float thr_lo, float e2, int lane) {
     const int wv = threadIdx.x >> 6;
     constexpr bool one_wave = KF_PLANE_WSLOTS == KF_CELLS_PER_WAVE;
@@ -822,7 +822,9 @@ k_cells_filter(CellsFilterArgs args) {
     const int x = tid % wc, band = tid / wc;
     const int ya = min(hc, band * rows_per), yb = band < bands ? min(hc, ya + rows_per) : ya;
     float* P = lds;                    // [h][w] the plane
-    int* list = (int*)(lds + h * w);   // [hc * wc] interior-weight cells from the front, the others from the back
+    // [hc * wc] cy << 7 | cx (both under 128): interior-weight cells from the front, the others from the back.  Two bytes
+    // per entry: with four the workgroup took 33.5 KB and only four fitted a CU's LDS -- 1024 of the 1152 of a batch of 64
+    unsigned short* list = (unsigned short*)(lds + h * w);
     if (tid == 0) sh.n_cand = 0;
     // ---- the plane to LDS, its maximum, its planar copy
     float* copy = a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w;
@@ -953,12 +955,12 @@ k_cells_filter(CellsFilterArgs args) {
     while (m_reg) {
         const int bit = __builtin_ctz(m_reg);
         m_reg &= m_reg - 1u;
-        list[at_r++] = ((ya + bit) << 7) | x;
+        list[at_r++] = (unsigned short)(((ya + bit) << 7) | x);
     }
     while (m_edge) {
         const int bit = __builtin_ctz(m_edge);
         m_edge &= m_edge - 1u;
-        list[n_cells - 1 - (at_e++)] = ((ya + bit) << 7) | x;
+        list[n_cells - 1 - (at_e++)] = (unsigned short)(((ya + bit) << 7) | x);
     }
     __syncthreads();
     // ---- the candidate filter on those cells
@@ -1550,7 +1552,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         PD_HIP(ctx, hipGetLastError());
         nhwc_verify = true;
     } else {
-    const size_t fused_lds = sizeof(float) * (size_t)h * w + sizeof(int) * (size_t)hc * wc;
+    const size_t fused_lds = sizeof(float) * (size_t)h * w + ((sizeof(unsigned short) * (size_t)hc * wc + 15) & ~(size_t)15);
     if (small_map && !split_cells && 256 / wc >= 1 && (hc + 256 / wc - 1) / (256 / wc) <= 32 && hc <= h && wc <= w && hc < 128 && wc < 128 &&
         fused_lds <= 40 * 1024) {
         CellsFilterArgs cf;
