@@ -414,6 +414,19 @@ void pd_up8_fill(Up8* u);
 int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
                            const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W,
                            float* absmax);
+// Issue priority of the calling wavefront (0 lowest .. 3): the short serial kernels of the chain raise theirs, so that
+// next to the chip-filling kernels of other contexts their few wavefronts are not served in turn with everybody else.
+// Levels (-DPD_SETPRIO=n, comparison builds): 1 = k_finish_peaks, k_match, k_parse_pack; 2 = k_verify as well; 3 = the
+// pair kernel too.  Measured at batch 64, 368^2, three alternating runs each: 1.369 M images/s without, 1.372 M with
+// level 1, 1.384 M with level 2, 1.347 M with level 3; at 656^2, batch 256: 343 k without, 346 k with level 2.
+#ifndef PD_SETPRIO
+#define PD_SETPRIO 2
+#endif
+#define PD_RAISE_PRIORITY(level)                                      \
+    do {                                                              \
+        if (PD_SETPRIO >= (level)) __builtin_amdgcn_s_setprio(3);     \
+    } while (0)
+
 // max over the wavefront of a non-negative float, rounded up one ulp (an infinity stays one), folded
 // into *dst (as bits)
 __device__ __forceinline__ void pd_wave_absmax(float m, float* dst) {

@@ -355,6 +355,7 @@ __device__ __forceinline__ void pair_scores_body(const PairArgs& a, const MultiS
 template <bool PRE>
 __global__ void __launch_bounds__(256)
 k_pair_scores(PairArgs a) {
+    PD_RAISE_PRIORITY(3);
     pair_scores_body<PRE, false>(a, nullptr);
 }
 
@@ -372,6 +373,7 @@ k_pair_scores_ms(PairArgs a, MultiSource ms) {
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 k_match(MatchArgs a) {
+    PD_RAISE_PRIORITY(1);
     extern __shared__ __align__(16) unsigned char dyn[];
     match_limb(a, blockIdx.x, blockIdx.y, threadIdx.x, dyn);
 }

@@ -750,6 +750,7 @@ static_assert(sizeof(pd_conn) == 24, "k_parse_pack copies a connection as three 
 
 __global__ void __launch_bounds__(256)
 k_parse_pack(ParsePackArgs a) {
+    PD_RAISE_PRIORITY(1);
     __shared__ WaveShared sh;
     __shared__ int s_pb[3][PD_N_PARTS + 1], s_lb[3][PD_N_LIMBS + 1];
     __shared__ long long s_tot[2];

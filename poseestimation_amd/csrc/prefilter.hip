@@ -1296,6 +1296,7 @@ struct VerifyArgs {
 template <bool FULL>
 __global__ void __launch_bounds__(VF_NT)
 k_verify(VerifyArgs a) {
+    PD_RAISE_PRIORITY(2);
     __shared__ double ypL[VF_CAND][3][28];
     __shared__ float hvL[8][VF_NT];
     __shared__ int rowL[VF_CAND][28];  // per candidate: first tap row | weight phase << 8 of its 27 window rows

@@ -189,11 +189,13 @@ __device__ __forceinline__ void finish_peaks_body(const SmoothArgs& a, PD_MULTI_
 template <int SRC>
 __global__ void __launch_bounds__(NTMAX)
 k_finish_peaks(SmoothArgs a) {
+    PD_RAISE_PRIORITY(1);
     finish_peaks_body<SRC>(a, nullptr, nullptr);
 }
 
 __global__ void __launch_bounds__(NTMAX)
 k_finish_peaks_ms(SmoothArgs a, const MultiSource* __restrict__ ms) {
+    PD_RAISE_PRIORITY(1);
     __shared__ float4 s_up8[8];
     if (threadIdx.x < 8) {
         const float* c = a.src.up8.c[threadIdx.x];
