@@ -8,7 +8,7 @@ Workloads (the configurations of BASELINE.json):
   b64_368           batch 64 at 368x368, single scale -- the configuration the metric is quoted on
   b256_656          batch 256 at 656x656, ~30 people per image
   ms4_b128_368      batch 128, four test scales (0.5, 1, 1.5, 2) averaged before the decode
-  stream_b1024_368  1024 images of 46x46x57 per step, streamed in chunks of 64 through the
+  stream_b1024_368  1024 images of 46x46x57 per step, streamed in chunks of 256 through the
                     round pipeline (skeleton buffers gathered once per round)
 
 One "step" decodes one batch (ms4, b64, b256) or one pass of 1024 images (stream) per GPU:
@@ -37,8 +37,11 @@ WORKLOADS = {
     'ms4_b128_368': dict(B=128, H=368, W=368, people=(1, 8), per_step=1, steps=30, kind='multiscale',
                          desc='synthetic batch 128 at 368x368, four test scales (0.5, 1, 1.5, 2: network outputs of '
                               '23^2, 46^2, 69^2, 92^2 x 57) resized, averaged and decoded'),
-    'stream_b1024_368': dict(B=64, H=368, W=368, people=(1, 8), per_step=16, steps=125, kind='single',
-                             desc='1024 synthetic images of 46x46x57 per step, streamed in 16 chunks of 64 through the '
+    # (chunks of 256: one rank's share of 1024 images is decoded in as few launches as keep three contexts busy;
+    # measured in the round pipeline, images/s by chunk size: 64 1.17 M, 128 1.47 M, 256 1.57 M, 512 1.59 M;
+    # PD_BENCH_CHUNK=n overrides)
+    'stream_b1024_368': dict(B=256, H=368, W=368, people=(1, 8), per_step=4, steps=125, kind='single',
+                             desc='1024 synthetic images of 46x46x57 per step, streamed in 4 chunks of 256 through the '
                                   'round pipeline'),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
@@ -131,7 +134,12 @@ def main():
                     help='GPU_MAX_HW_QUEUES for this process when the environment asks for fewer '
                          '(0: leave it; -1: 8)')
     args = ap.parse_args()
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if os.environ.get('PD_BENCH_CHUNK'):      # comparison runs: the same images per step in chunks of another size
+        c = int(os.environ['PD_BENCH_CHUNK'])
+        wl['desc'] = wl['desc'].replace('%d chunks of %d' % (wl['per_step'], wl['B']), '%d chunks of %d' % (wl['B'] * wl['per_step'] // c, c))
+        wl['per_step'] = wl['B'] * wl['per_step'] // c
+        wl['B'] = c
     if args.steps <= 0:
         args.steps = wl['steps']
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -650,8 +658,9 @@ def run_single(env):
         result_bytes = int(len(res0['raw'])) if 'raw' in res0 else int(res0['peaks'].nbytes + res0['persons'].nbytes)
         must_bytes = B * n * 57 * 4.0 + result_bytes
         decode_s = step_s / per_step
-        pmc = pmc_traffic(args.workload if args.workload != 'stream_b1024_368' else 'b64_368')
-        step_traffic = pmc.get('step_hbm_bytes') if pmc else None
+        pmc = pmc_traffic(args.workload)
+        # (the counters were read on decodes of pmc['batch'] images; other chunk sizes scale them)
+        step_traffic = pmc.get('step_hbm_bytes') * (B / float(pmc.get('batch', B))) if pmc else None
         roofline = {
             'bound': 'hbm', 'kernel': 'whole decode of one batch (all kernels of the chain, %d contexts overlapped)' % len(engs),
             'achieved': must_bytes / decode_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -703,7 +712,7 @@ def run_single(env):
             'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': desc, 'name': args.workload, 'batch_per_gpu': B * per_step, 'mode': args.mode,
+            'config': {'workload': desc, 'name': args.workload, 'batch_per_gpu': B * per_step, 'images_per_decode': B, 'mode': args.mode,
                        'contexts_per_gpu': len(engs), 'streams_per_gpu': n_ctx, 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
                        'people_per_image': list(people) if isinstance(people, tuple) else people,
                        'inputs': 'device-resident network outputs, %d distinct batches of %.1f MB used in turn '

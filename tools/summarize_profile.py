@@ -65,6 +65,12 @@ for k in sorted(set(fetch) | set(write)):
     if 'resize' in name:
         resize += (2.0 * f + w) * round(per_step)
 out['step_hbm_bytes'] = step
+try:    # images per decode of the run the counters were read on (bench.py scales by it for other chunk sizes)
+    with open(os.path.join(SRC, 'fetch_bench.json')) as fh:
+        cfg = json.loads(fh.read().strip().splitlines()[-1])['config']
+    out['batch'] = cfg.get('images_per_decode', cfg.get('batch_per_gpu'))
+except Exception:
+    pass
 if resize:
     out['resize_stage_hbm_bytes'] = resize
 with open(os.path.join(DST, 'pmc_%s.json' % workload), 'w') as fh:
