@@ -824,11 +824,12 @@ k_parse_pack(ParsePackArgs a) {
             tot_p += np;
             if (j < b) pre_p += np;
         }
-        for (int e = lane; e < k.B * PD_N_LIMBS; e += 64) {
-            const long long nc = max(0, k.limb_count[e]);
-            tot_c += nc;
-            if (e / PD_N_LIMBS < b) pre_c += nc;
-        }
+        if (k.have_conns)
+            for (int e = lane; e < k.B * PD_N_LIMBS; e += 64) {
+                const long long nc = max(0, k.limb_count[e]);
+                tot_c += nc;
+                if (e / PD_N_LIMBS < b) pre_c += nc;
+            }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             pre_p += __shfl_xor(pre_p, d);
@@ -838,7 +839,7 @@ k_parse_pack(ParsePackArgs a) {
         }
         // where the parts / limbs of this image start in its runs of peaks / connections
         if (lane <= PD_N_PARTS) s_pb[w][lane] = k.part_base[b * (PD_N_PARTS + 1) + lane];
-        const int my_nc = lane < PD_N_LIMBS ? max(0, k.limb_count[b * PD_N_LIMBS + lane]) : 0;
+        const int my_nc = lane < PD_N_LIMBS && k.have_conns ? max(0, k.limb_count[b * PD_N_LIMBS + lane]) : 0;
         int incl = my_nc;
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) {
@@ -850,7 +851,7 @@ k_parse_pack(ParsePackArgs a) {
         pd_wave_sync();
         if (w == 0) {
             if (lane < PD_N_PARTS) PD_PUT((int32_t*)(k.res + k.lay.off_part) + b * PD_N_PARTS + lane, k.part_count[b * PD_N_PARTS + lane]);
-            if (lane < PD_N_LIMBS) PD_PUT((int32_t*)(k.res + k.lay.off_limb) + b * PD_N_LIMBS + lane, k.limb_count[b * PD_N_LIMBS + lane]);
+            if (lane < PD_N_LIMBS) PD_PUT((int32_t*)(k.res + k.lay.off_limb) + b * PD_N_LIMBS + lane, k.have_conns ? k.limb_count[b * PD_N_LIMBS + lane] : 0);
             if (lane == 0) {
                 s_tot[0] = tot_p;
                 s_tot[1] = tot_c;
@@ -858,7 +859,10 @@ k_parse_pack(ParsePackArgs a) {
         }
         pd_peak* out_peaks = (pd_peak*)(k.res + k.lay.off_payload) + pre_p;
         pd_conn* out_conns = (pd_conn*)(k.res + k.lay.off_payload + tot_p * sizeof(pd_peak)) + pre_c;
-        const int n_p = s_pb[w][PD_N_PARTS], n_c = s_lb[w][PD_N_LIMBS];
+        // a caller's buffer (cap != 0) gets its peaks and connections only if all of them fit
+        const bool lists_fit = k.cap == 0 || k.lay.off_payload + (unsigned long long)tot_p * sizeof(pd_peak) +
+                                                     (unsigned long long)tot_c * sizeof(pd_conn) <= k.cap;
+        const int n_p = lists_fit ? s_pb[w][PD_N_PARTS] : 0, n_c = lists_fit ? s_lb[w][PD_N_LIMBS] : 0;
         for (int i = w * 64 + lane; i < n_p; i += 192) {
             int p = 0;
             while (i >= s_pb[w][p + 1]) ++p;
@@ -887,12 +891,17 @@ k_parse_pack(ParsePackArgs a) {
     const long long n_peaks = s_tot[0], n_conns = s_tot[1];
     double* out_persons = (double*)(k.res + k.lay.off_payload + n_peaks * sizeof(pd_peak) + n_conns * sizeof(pd_conn)) + pre * 20;
     double* staged = a.p.persons + (size_t)b * a.p.max_persons * 20;
+    // bytes of the buffer up to the end of this image's rows: a caller's buffer (cap != 0) gets the rows of the images
+    // that fit; the last image reports what the whole result needs, and a reader looks at that before the payload
+    const unsigned long long rows_end = k.lay.off_payload + (unsigned long long)n_peaks * sizeof(pd_peak) +
+                                        (unsigned long long)n_conns * sizeof(pd_conn) + (unsigned long long)(pre + count) * 20 * sizeof(double);
+    const bool rows_fit = k.cap == 0 || rows_end <= k.cap;
     if (direct) {
         if (keep) {
             wave_write_row(staged + (size_t)rank * 20, 0, lane, sh, st);
-            wave_write_row(out_persons + (size_t)rank * 20, mirror, lane, sh, st);
+            if (rows_fit) wave_write_row(out_persons + (size_t)rank * 20, mirror, lane, sh, st);
         }
-    } else if (count > 0) {
+    } else if (count > 0 && rows_fit) {
         // the table form left the rows in the staging area (stored write-through; drained here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int i = lane; i < count * 20; i += 64) {
@@ -912,7 +921,7 @@ k_parse_pack(ParsePackArgs a) {
             PD_PUT(head + 2, (int64_t)n_conns);
             PD_PUT(head + 3, (int64_t)(pre + count));
             PD_PUT(head + 4, (int64_t)(bad == 0x7fffffff ? -1 : bad));
-            PD_PUT(head + 5, (int64_t)0);  // the library's own buffer holds any result by construction
+            PD_PUT(head + 5, (int64_t)(rows_fit ? 0 : rows_end));  // != 0: the caller's buffer is too small, ignore the payload
         }
         for (int j = k.B + lane; j < a.max_batch; j += 64)
             __hip_atomic_store(a.sync + PP_WORDS + j, tag << PP_TAG_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -976,17 +985,20 @@ static void fill_pack_args(pd_ctx* ctx, PackArgs& a) {
     a.zero_words = (int)(ctx->zero_bytes / sizeof(int32_t));
 }
 
-// Whether person assembly and packing of the current decode can share a launch: the library's
-// own result buffer (no capacity to check before anything is written), no skeleton buffer, the
-// wavefront form of the assembly with its hand-over inside the kernel.  PD_SEPARATE_PACK=1 in
+// Whether person assembly and packing of the current decode can share a launch: one destination
+// (the library's own result buffer, or a skeleton buffer alone, whose capacity the kernel checks as it
+// goes), the wavefront form of the assembly with its hand-over inside the kernel.  PD_SEPARATE_PACK=1 in
 // the environment keeps the two launches (comparison runs).
 bool pd_parse_pack_fused(const pd_ctx* ctx) {
     static const bool separate = [] {
         const char* v = getenv("PD_SEPARATE_PACK");
         return v && *v && *v != '0';
     }();
-    return !separate && ctx->pack_sync && ctx->impl != PD_IMPL_SIMPLE && !ctx->dbg_found && !ctx->skel_dst &&
-           ctx->host_results && ctx->res_user_cap == 0 && ctx->have_peaks && ctx->have_conns &&
+    // (either the library's own result buffer, or a skeleton buffer alone: with both, two packing launches follow the assembly)
+    const bool own = !ctx->skel_dst && ctx->host_results && ctx->res_user_cap == 0;
+    const bool skeleton_alone = ctx->skel_dst && !ctx->host_results;
+    return !separate && ctx->pack_sync && ctx->impl != PD_IMPL_SIMPLE && !ctx->dbg_found && (own || skeleton_alone) &&
+           ctx->have_peaks && ctx->have_conns &&
            (size_t)ctx->cfg.max_persons * 20 <= (size_t)WAVE_CONNS * 4 && ctx->cfg.max_persons < PP_NOT_OK;
 }
 
@@ -1005,6 +1017,12 @@ int pd_launch_parse_pack(pd_ctx* ctx) {
     a.p.dbg_found = nullptr;
     ctx->have_persons = 1;
     fill_pack_args(ctx, a.k);
+    if (ctx->skel_dst) {  // the caller's device buffer: the same layout without the connection lists, its capacity checked
+        a.k.res = ctx->skel_dst;
+        a.k.res2 = nullptr;
+        a.k.cap = ctx->skel_cap;
+        a.k.have_conns = 0;
+    }
     a.sync = ctx->pack_sync;
     a.max_batch = ctx->cfg.max_batch;
     pd_prof_begin(ctx, PD_STAGE_PARSE);

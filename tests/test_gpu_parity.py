@@ -692,6 +692,50 @@ def test_skeleton_only_decode_has_nothing_to_fetch(pdec):
     eng.close()
 
 
+def test_skeleton_only_decode_checks_the_capacity_as_it_writes(pdec):
+    """A context that writes a skeleton buffer alone assembles and packs in one launch, which learns the size of the
+    result as it goes: whatever the capacity, nothing is written beyond it, the count tables always arrive, and the
+    header says what the whole result needs when it does not fit (a reader then ignores the payload)."""
+    import torch
+    from poseestimation_amd import _ffi, sharding, synth
+    H = W = 184
+    B = 6
+    heat, paf = synth.batch(B, H, W, (2, 5), seed0=170, paf_order='xy')
+    dh, dp = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    want = pdec.DecodeEngine(B, H, W, mode='D').decode_batch(heat, paf).packed
+    n_peaks, n_persons = len(want['peaks']), len(want['persons'])
+    off_pay = int(_ffi.res_layout(B)[4])
+    need = off_pay + 16 * n_peaks + 160 * n_persons
+    eng = pdec.DecodeEngine(max_batch=B, max_h=H, max_w=W, mode='D')
+    eng.ctx.set_host_results(False)
+    buf = torch.empty(1 << 17, dtype=torch.uint8, device='cuda')
+    # exactly enough; the tables and a little; the peaks and some of the person rows; one byte short
+    for cap in (need, off_pay + 64, off_pay + 16 * n_peaks + 160 * (n_persons // 2) + 8, need - 1):
+        cap16 = cap            # (the capacity need not be a multiple of anything)
+        buf.fill_(255)
+        eng.ctx.set_skeleton_buffer(buf.data_ptr(), cap16)
+        eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), B, 23, 23, (H, W))
+        eng.ctx.sync()
+        raw = buf.cpu().numpy()
+        assert np.all(raw[cap16:] == 255), cap                        # never past the capacity
+        head = raw[:64].view(np.int64)
+        assert (head[0], head[1], head[3], head[4]) == (B, n_peaks, n_persons, -1)
+        part = raw[_ffi.res_layout(B)[0]:_ffi.res_layout(B)[0] + 4 * B * 18].view(np.int32).reshape(B, 18)
+        assert np.array_equal(part, want['part_count'])
+        if cap >= need:
+            assert head[5] == 0
+            got = sharding.SkeletonGather.results(raw[None, None, :cap16])[0]
+            for key in ('part_count', 'person_count', 'status', 'peaks', 'persons'):
+                assert np.array_equal(got[key], want[key]), key
+        else:
+            assert head[5] == need, (cap, head[5], need)
+            with pytest.raises(ValueError):
+                sharding.SkeletonGather.results(raw[None, None, :cap16])
+            if cap < off_pay + 16 * n_peaks:
+                assert np.all(raw[off_pay:cap16] == 255)              # no list that does not fit whole is begun
+    eng.close()
+
+
 def test_submit_launches_from_the_context_thread(pdec):
     """pd_submit / pd_flush: decodes queued for the context's launcher thread write the same
     skeleton buffers as direct calls, in order, and errors surface at the flush."""
