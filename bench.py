@@ -184,8 +184,16 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
+    # PD_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path where the ranks cannot have a GPU each (RCCL refuses two
+    # ranks on one GPU): the ranks share the GPUs there are, the gathers go through host memory.  Its rates mean nothing.
+    backend = os.environ.get('PD_BENCH_BACKEND', 'nccl')
+    if backend == 'gloo':
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if use_dist:
+    if use_dist and backend == 'gloo':
+        dist.init_process_group('gloo')
+        dist.barrier()
+    elif use_dist:
         # RCCL writes a version banner to stdout when its first communicator comes up; stdout
         # carries the JSON line only, so the banner is sent to stderr
         sys.stdout.flush()
@@ -207,7 +215,8 @@ def main():
             os.close(saved_stdout)
 
     env = dict(args=args, wl=wl, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist, rounds=rounds,
-               torch=torch, dist=dist, all_cores=all_cores, token=torch.zeros(1, device='cuda') if use_dist else None)
+               torch=torch, dist=dist, all_cores=all_cores, comm_device='cpu' if backend == 'gloo' else 'cuda',
+               token=torch.zeros(1, device='cpu' if backend == 'gloo' else 'cuda') if use_dist else None)
     out = run_multiscale(env) if multiscale else run_single(env)
     parity_failed = False
     if rank == 0 and world == 1 and not use_dist and not args.no_extras and not profiled and args.workload == 'b64_368' \
@@ -356,7 +365,7 @@ def max_over_ranks(env, dt):
     if not env['use_dist']:
         return dt
     torch, dist = env['torch'], env['dist']
-    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    t = torch.tensor([dt], dtype=torch.float64, device=env['comm_device'])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -499,6 +508,9 @@ def run_single(env):
             for e in pool:
                 e.ctx.flush()
             td = time.perf_counter()
+            if not g.on_gpu:        # (gloo rehearsal: the gather reads the send buffers from the host side)
+                for e in pool:
+                    e.ctx.sync()
             g.start(s)
             te = time.perf_counter()
             host_t[0] += tb - ta
@@ -761,6 +773,32 @@ def run_single(env):
                 out['cpu_baseline_all_cores'] = env['all_cores']
             out['parity_checked_images'] = ncpu
             out['parity_ok'] = bool(ok)
+        if use_dist and not args.no_cpu and gather is not None and n_scenes == B:
+            # N > 1: images of every rank, as they arrived on rank 0 through the gather, against the oracle on that
+            # rank's inputs (rendered again here from their seeds); peaks and person rows are what the gather carries
+            from oracle import decode_ref as ref
+            r_all = Results(res0, eng.mode)
+            ok, checked = True, 0
+            for rk in range(world):
+                for b in sorted({0, B - 1}):
+                    src = (b + buf0) % B
+                    hm, pm = synth.batch(1, H, W, people, seed0=rk * B + src, paf_order='xy' if args.mode == 'D' else 'yx')
+                    hf = ref.resize_cubic(hm[0], fx=8, fy=8).astype(np.float64)
+                    pf = ref.resize_cubic(pm[0], fx=8, fy=8).astype(np.float64)
+                    peaks = ref.get_peaks(hf, 0.1, args.mode, use_scipy=True)
+                    conns, special = ref.get_connections(peaks, pf, 0.05, args.mode)
+                    subset = ref.multi_person_parse(peaks, conns, special, args.mode)
+                    g = r_all.subset(rk * B + b)
+                    gp = r_all.all_peaks(rk * B + b)
+                    ok = ok and g.shape == subset.shape and np.array_equal(g[:, :18], subset[:, :18]) \
+                        and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0) \
+                        and [len(x) for x in gp] == [len(x) for x in peaks] \
+                        and all(int(a[0]) == int(c[0]) and int(a[1]) == int(c[1]) and float(a[2]) == float(c[2])
+                                for x, y in zip(gp, peaks) for a, c in zip(x, y))
+                    checked += 1
+            out['parity_checked_images'] = checked
+            out['parity_ok'] = bool(ok)
+            out['parity_note'] = 'two images of every rank from the last gathered round, as rank 0 received them'
     for e in engs:
         e.close()
     return out
@@ -831,6 +869,9 @@ def run_multiscale(env):
                 for j in range(k):
                     gather.point(s, j, j)
                     decode(engs[j])
+                if not gather.on_gpu:
+                    for e in engs[:k]:
+                        e.ctx.sync()
                 gather.start(s)
                 busy[s] = True
                 done += k
@@ -986,6 +1027,27 @@ def run_multiscale(env):
                                              'host has %d cpus' % (ncpu, os.cpu_count())}
             out['parity_checked_images'] = ncpu
             out['parity_ok'] = bool(ok)
+        if env['use_dist'] and not args.no_cpu:
+            # N > 1: one image of every rank, as it arrived on rank 0 through the gather, against the oracle on that
+            # rank's inputs (rendered again here from their seeds)
+            from oracle import decode_ref as ref
+            r = Results(last, engs[0].mode)
+            ok = True
+            for rk in range(world):
+                rrng = np.random.RandomState(100003 + rk)
+                cnt = [int(rrng.randint(people[0], people[1] + 1)) for _ in range(NSCENE)]
+                b = (rk * 5) % NSCENE
+                outs = [synth.scene(H, W, cnt[b], 7000 + rk * NSCENE + b, paf_order='xy' if args.mode == 'D' else 'yx', scale=sc)
+                        for sc in SCALES]
+                want_h, want_p = ref.upsample_average([o[0] for o in outs], [o[1] for o in outs], [(0, 0)] * 4, (H, W))
+                cand, peaks, subset = ref.decode(want_h, want_p, 0.1, 0.05, args.mode)
+                g = r.subset(rk * B + b)
+                ok = ok and g.shape == subset.shape and np.array_equal(g[:, :18], subset[:, :18]) \
+                    and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0) \
+                    and np.array_equal(r.candidate(rk * B + b)[:, :2], cand[:, :2])
+            out['parity_checked_images'] = world
+            out['parity_ok'] = bool(ok)
+            out['parity_note'] = 'one image of every rank from the last gathered step, as rank 0 received it'
     for e in engs:
         e.close()
     return out
