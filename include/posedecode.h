@@ -55,7 +55,7 @@ typedef struct {
     int32_t max_batch;           /* images per call */
     int32_t max_h, max_w;        /* full-resolution image size */
     int32_t max_peaks_per_part;  /* per image and body part */
-    int32_t max_persons;         /* per image, before pruning */
+    int32_t max_persons;         /* per image, before pruning; at most 960 (160 bytes of LDS per open person) */
     int32_t max_pairs_per_image; /* sum over limbs of nA*nB */
     int32_t fullres;             /* != 0: allocate the full-resolution planes needed by
                                     pd_upsample_avg / pd_load_fullres */

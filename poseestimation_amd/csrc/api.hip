@@ -66,6 +66,11 @@ extern "C" int pd_create(const pd_config* cfg, pd_ctx** out) {
         snprintf(g_err, sizeof(g_err), "pd_create: capacities must be positive");
         return PD_E_INVALID;
     }
+    if (cfg->max_persons > PD_MAX_PERSONS_LIMIT) {  // the table form of the person assembly keeps an image's rows in LDS
+        snprintf(g_err, sizeof(g_err), "pd_create: max_persons %d exceeds %d (160 bytes of LDS per open person)", cfg->max_persons,
+                 PD_MAX_PERSONS_LIMIT);
+        return PD_E_INVALID;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         snprintf(g_err, sizeof(g_err), "pd_create: no HIP device visible");

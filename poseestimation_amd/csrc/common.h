@@ -414,6 +414,10 @@ void pd_up8_fill(Up8* u);
 int pd_launch_upsample_avg(pd_ctx* ctx, int n_scales, const float* const* srcs, int C, int B, const int32_t* hs,
                            const int32_t* ws, const int32_t* crop_h, const int32_t* crop_w, double* dst, int H, int W,
                            float* absmax);
+// Open persons per image a context can be made for: the table form of the person assembly (k_parse) holds the rows of an
+// image, 20 doubles each, in one workgroup's LDS (150 KB of the CU's 160).
+#define PD_MAX_PERSONS_LIMIT 960
+
 // Issue priority of the calling wavefront (0 lowest .. 3): the short serial kernels of the chain raise theirs, so that
 // next to the chip-filling kernels of other contexts their few wavefronts are not served in turn with everybody else.
 // Levels (-DPD_SETPRIO=n, comparison builds): 1 = k_finish_peaks, k_match, k_parse_pack; 2 = k_verify as well; 3 = the

@@ -943,6 +943,14 @@ int pd_launch_parse(pd_ctx* ctx) {
     a.person_count = ctx->person_count;
     a.status = ctx->status;
     const size_t lds = (size_t)a.max_persons * 20 * sizeof(double);
+    if (lds > 64 * 1024) {  // beyond the default limit of dynamic LDS (pd_create keeps max_persons within 150 KB)
+        static size_t allowed[64];  // per device
+        size_t& have = allowed[ctx->cfg.device_id >= 0 && ctx->cfg.device_id < 64 ? ctx->cfg.device_id : 0];
+        if (have < lds) {
+            PD_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_parse), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            have = 150 * 1024;
+        }
+    }
     pd_prof_begin(ctx, PD_STAGE_PARSE);
     a.dbg_found = ctx->dbg_found;
     if (ctx->impl == PD_IMPL_SIMPLE || ctx->dbg_found) {

@@ -692,6 +692,46 @@ def test_skeleton_only_decode_has_nothing_to_fetch(pdec):
     eng.close()
 
 
+def test_person_tables_up_to_the_limit(pdec):
+    """Hundreds of open persons per image (random fields: every second connection opens a row that is pruned in the
+    end): a context with small tables reports the overflow, one with the largest tables pd_create allows (the table
+    form of the assembly keeps an image's rows in LDS, beyond the default limit of dynamic LDS) gives the oracle's
+    rows; larger tables are refused."""
+    from poseestimation_amd import _ffi
+    rng = np.random.default_rng(13 * 100003 + 357)
+
+    def smooth(shape, passes):
+        a = rng.standard_normal(shape).astype(np.float32)
+        for _ in range(passes):
+            a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / np.float32(5)
+        return a / np.float32(np.abs(a).max() + 1e-6)
+    h = w = 17
+    heat = np.abs(smooth((h, w, 19), 1)) * np.float32(0.6)
+    paf = smooth((h, w, 38), 2) * np.float32(0.5)
+    paf[..., 0::2] += np.float32(0.3)
+    H, W = 8 * h, 8 * w
+    hf = ref.resize_cubic(heat, fx=8, fy=8).astype(np.float64)
+    pf = ref.resize_cubic(paf, fx=8, fy=8).astype(np.float64)
+    peaks = ref.get_peaks(hf, 0.1, 'P', use_scipy=True)
+    conns, special = ref.get_connections(peaks, pf, 0.02, 'P')
+    subset = ref.multi_person_parse(peaks, conns, special, 'P')
+    assert sum(len(c) for c in conns) > 300           # far more rows are opened than the 128 of the small context
+    small = pdec.DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='P', max_peaks_per_part=256, max_persons=128,
+                              max_pairs_per_image=400000)
+    with pytest.raises(_ffi.DecodeOverflow):
+        small.decode_batch(np.stack([heat, heat]), np.stack([paf, paf]), thre1=0.1, thre2=0.02)
+    small.close()
+    big = pdec.DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='P', max_peaks_per_part=256, max_persons=960,
+                            max_pairs_per_image=400000)
+    res = big.decode_batch(np.stack([heat, heat[::-1].copy()]), np.stack([paf, paf[::-1].copy()]), thre1=0.1, thre2=0.02)
+    gio.assert_peaks_equal(res.all_peaks(0), peaks, exact_score=True)
+    gio.assert_persons_equal(res.subset(0), subset, RTOL)
+    big.close()
+    with pytest.raises(Exception) as info:
+        pdec.DecodeEngine(max_batch=2, max_h=H, max_w=W, mode='P', max_persons=961)
+    assert '960' in str(info.value)
+
+
 def test_skeleton_only_decode_checks_the_capacity_as_it_writes(pdec):
     """A context that writes a skeleton buffer alone assembles and packs in one launch, which learns the size of the
     result as it goes: whatever the capacity, nothing is written beyond it, the count tables always arrive, and the
