@@ -9,7 +9,7 @@ With --multiscale: two to four random test scales between 0.4 and 2.2 with non-z
 network outputs per scale, through pd_decode_multiscale (no stored maps) against the oracle's resize + average +
 decode (predict.py:49-254).
 
-Usage (on a GPU box): python tools/fuzz_decode.py [--cases 200] [--seed 0] [--batch 4] [--multiscale | --large | --images]
+Usage (on a GPU box): python tools/fuzz_decode.py [--cases 200] [--seed 0] [--batch 4] [--multiscale | --large | --images | --shapes]
 Prints one line per mismatch and a summary; exit status 1 if anything differed."""
 import argparse
 import os
@@ -157,6 +157,51 @@ def image_cases(args):
     return 1 if bad else 0
 
 
+def shape_cases(args):
+    """Degenerate geometries: maps of one to three network pixels a side, strips one to five pixels wide and up to 200
+    long, with random crops; uniform noise (so every part has peaks wherever the map allows one)."""
+    bad = n = 0
+    shapes = [(1, 1), (1, 2), (2, 1), (2, 2), (1, 3), (3, 3), (1, 40), (40, 1), (2, 64), (64, 2), (3, 127), (127, 3), (1, 128), (128, 1),
+              (5, 200), (200, 5)]
+    for case in range(args.cases):
+        h, w = shapes[case % len(shapes)]
+        rng = np.random.default_rng(args.seed * 100003 + 5000 + case)
+        H, W = 8 * h - int(rng.integers(0, 8)), 8 * w - int(rng.integers(0, 8))
+        heat = rng.random((2, h, w, 19)).astype(np.float32)
+        paf = rng.random((2, h, w, 38)).astype(np.float32) - np.float32(0.3)
+        mode = 'DP'[case % 2]
+        tag = 'shape case %d (seed %d): maps %dx%d -> %dx%d mode %s' % (case, args.seed, h, w, H, W, mode)
+        eng = pdec.DecodeEngine(max_batch=2, max_h=8 * h, max_w=8 * w, mode=mode, max_peaks_per_part=512, max_persons=960,
+                                max_pairs_per_image=1000000)
+        try:
+            res = eng.decode_batch(heat, paf, out_hw=(H, W))
+        except IndexError:
+            eng.close()
+            continue
+        except Exception as exc:
+            bad += 1
+            print(tag, ': decode raised', repr(exc))
+            eng.close()
+            continue
+        for b in range(2):
+            peaks, conns, special, subset = oracle(heat[b], paf[b], H, W, mode, 0.1, 0.05)
+            if subset is IndexError:
+                continue
+            try:
+                gio.assert_peaks_equal(res.all_peaks(b), peaks, exact_score=True)
+                g_conns, g_special = res.connections(b)
+                assert g_special == special, ('special', g_special, special)
+                gio.assert_conns_equal(g_conns, conns, 1e-9)
+                gio.assert_persons_equal(res.subset(b), subset, 1e-9)
+                n += 1
+            except AssertionError as exc:
+                bad += 1
+                print(tag, 'image', b, ':', str(exc)[:400].replace('\n', ' | '))
+        eng.close()
+    print('%d shape cases: %d images equal, %d mismatches' % (args.cases, n, bad))
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
@@ -164,6 +209,7 @@ def main():
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--multiscale', action='store_true')
     ap.add_argument('--images', action='store_true', help='the image resize + pad in front of the network instead of the decode')
+    ap.add_argument('--shapes', action='store_true', help='maps of one to three pixels a side and long strips')
     ap.add_argument('--large', action='store_true', help='maps of 60..91 x 70..91 network pixels')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
@@ -171,6 +217,8 @@ def main():
         return multiscale_cases(args)
     if args.images:
         return image_cases(args)
+    if args.shapes:
+        return shape_cases(args)
     bad = 0
     index_errors = retried = 0
     totals = [0, 0, 0]
