@@ -347,6 +347,17 @@ def detect_latency(env):
                     'cpu_restatement_ms: oracle/decode_ref.py upsample_average + decode of the same outputs, one thread'}
 
 
+def preheat(env, some_decodes):
+    """Keeps the GPU busy with decodes for PD_BENCH_PREHEAT_MS (default 200) before the warm-up steps.  With several
+    ranks the decision to go on is taken on the slowest rank's clock, so that all ranks issue the same gathers."""
+    want = float(os.environ.get('PD_BENCH_PREHEAT_MS', '200')) * 1e-3
+    t0 = time.perf_counter()
+    while want > 0:
+        some_decodes()
+        if max_over_ranks(env, time.perf_counter() - t0) >= want:
+            break
+
+
 def make_barrier(env):
     torch, dist = env['torch'], env['dist']
 
@@ -560,6 +571,11 @@ def run_single(env):
             # (the ranks must agree on the number of gathers: the slowest rank's figure decides)
             quiet = quiet + 4 if max_over_ranks(env, host_t[5]) < 1e-3 else 0
             total += 4
+    # The chip's clocks follow its load with a delay: behind a few milliseconds of warm-up a timed region of a millisecond
+    # ran 5 to 20 % slower than the same region a moment later (regions of 20 steps one after the other in one process:
+    # 0.94-1.18 M images/s for the first, 1.20-1.25 M for every later one).  So the chip is kept busy for a fifth of a
+    # second before the warm-up steps asked for; PD_BENCH_PREHEAT_MS=0 leaves it out.
+    preheat(env, lambda: run(len(engs) * (GATHER_DEPTH if gather is not None else 1) * 2))
     run(args.warmup * per_step)
     for e in engs:
         e.ctx.profile_read()
@@ -724,7 +740,7 @@ def run_single(env):
             'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': desc, 'name': args.workload, 'batch_per_gpu': B * per_step, 'images_per_decode': B, 'mode': args.mode,
+            'config': {'workload': desc, 'name': args.workload, 'batch_per_gpu': B * per_step, 'images_per_decode': B, 'mode': args.mode, 'preheat_ms': float(os.environ.get('PD_BENCH_PREHEAT_MS', '200')),
                        'contexts_per_gpu': len(engs), 'streams_per_gpu': n_ctx, 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
                        'people_per_image': list(people) if isinstance(people, tuple) else people,
                        'inputs': 'device-resident network outputs, %d distinct batches of %.1f MB used in turn '
@@ -907,6 +923,7 @@ def run_multiscale(env):
     run(2 * len(engs))
     if gather is not None:
         run(24)     # past the one slow gather among a process group's first twenty or so (see run_single)
+    preheat(env, lambda: run(2 * len(engs)))      # (the chip's clocks: see run_single)
     run(min(args.warmup, 4))
     for e in engs:
         e.ctx.profile_read()
