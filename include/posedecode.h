@@ -393,6 +393,14 @@ const char* pd_comm_last_error(pd_comm* comm);
 int pd_gather(pd_comm* comm, pd_ctx* const* ctxs, int n_ctx, int root, void* recv_host,
               uint64_t recv_capacity, uint64_t* sizes, uint64_t* total_bytes);
 
+/* Part of the same exchange, for callers that gather fixed-size slices themselves (one slice of
+ * `capacity` bytes per decode, n_slices of them back to back at src_dev -- what a framework's gather
+ * collective delivers): stores, of every slice, the bytes its header says are in use (header, count
+ * tables, peaks, person rows; the tables alone if the header reports a buffer that was too small) to the
+ * same offsets of dst, which may be pinned host memory.  Queued on `stream`; the bytes of dst behind a
+ * slice's used part are left as they were.  capacity: a multiple of 16; both addresses 16-byte aligned. */
+int pd_copy_used_skeletons(const void* src_dev, void* dst, int n_slices, uint64_t capacity, void* stream);
+
 /* ---- test hook (host only, touches no GPU) ----
  * The linear operator the sparse multi-scale peak stage evaluates for one axis of one scale --
  * scipy's Gaussian (sigma 3, reflect) after the second cubic resize (crop -> L outputs, predict.py:65)

@@ -23,7 +23,7 @@ EXPORTS = ['pd_create', 'pd_destroy', 'pd_last_error', 'pd_version', 'pd_set_mod
            'pd_decode_batch', 'pd_decode_fullres', 'pd_pack', 'pd_sync_totals', 'pd_fetch',
            'pd_debug_smoothed', 'pd_packed_device', 'pd_profile', 'pd_profile_read', 'pd_results_host', 'pd_filter_stats', 'pd_profile_stages', 'pd_set_skeleton_buffer', 'pd_submit', 'pd_flush', 'pd_set_graph_replay', 'pd_set_host_results',
            'pd_decode_batch_static', 'pd_coco_rows', 'pd_image_resize_shape', 'pd_image_resize_pad', 'pd_render',
-           'pd_debug_found', 'pd_test_ms_axis', 'pd_comm_unique_id', 'pd_comm_create', 'pd_comm_destroy', 'pd_comm_last_error', 'pd_gather']
+           'pd_debug_found', 'pd_test_ms_axis', 'pd_comm_unique_id', 'pd_comm_create', 'pd_comm_destroy', 'pd_comm_last_error', 'pd_gather', 'pd_copy_used_skeletons']
 
 STAGES = ['resize', 'smooth_nms', 'sort', 'pairs', 'match', 'parse', 'pack', 'filter', 'verify', 'planar', 'cells']
 
@@ -148,6 +148,7 @@ def lib():
     L.pd_comm_last_error.argtypes = [vp]
     L.pd_comm_last_error.restype = C.c_char_p
     L.pd_gather.argtypes = [vp, C.POINTER(vp), i32, i32, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pd_copy_used_skeletons.argtypes = [vp, vp, i32, C.c_uint64, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ('pd_last_error', 'pd_version', 'pd_stream', 'pd_comm_last_error'):

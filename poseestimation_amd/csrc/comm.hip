@@ -286,3 +286,46 @@ extern "C" int pd_gather(pd_comm* c, pd_ctx* const* ctxs, int n_ctx, int root, v
                 (unsigned long long)total, (unsigned long long)recv_capacity);
     return PD_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// The root's way to its host: of every gathered skeleton buffer only the bytes in use.  The slices of
+// a round are fixed-size (their capacity is what the largest result may take; a typical one fills half
+// of it), and at eight ranks a plain copy of all of them is most of what a PCIe link carries.  One
+// workgroup per slice reads the slice's header, works out where its payload ends and stores that much
+// to the same offset of the destination, which may be host memory the device can write (pinned).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_copy_used(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, unsigned long long capacity) {
+    const unsigned char* s = src + (size_t)blockIdx.x * capacity;
+    unsigned char* d = dst + (size_t)blockIdx.x * capacity;
+    const long long* head = (const long long*)s;
+    const long long B = head[0], n_peaks = head[1], n_conns = head[2], n_persons = head[3], need = head[5];
+    unsigned long long used = 64;   // a slice no decode has written: its header alone (the reader rejects it)
+    if (B >= 1 && B <= (1 << 20) && n_peaks >= 0 && n_conns >= 0 && n_persons >= 0) {
+        const unsigned long long tables = pd_res_layout((int)B).off_payload;
+        used = need != 0 ? tables
+                         : tables + (unsigned long long)n_peaks * sizeof(pd_peak) + (unsigned long long)n_conns * sizeof(pd_conn) +
+                               (unsigned long long)n_persons * 20 * sizeof(double);
+    }
+    if (used > capacity) used = capacity;
+    const size_t n16 = (size_t)((used + 15) / 16);  // (the capacity is a multiple of 16: rounding up stays inside the slice)
+    const uint4* s4 = (const uint4*)s;
+    uint4* d4 = (uint4*)d;
+    for (size_t i = threadIdx.x; i < n16; i += 256) d4[i] = s4[i];
+}
+
+extern "C" int pd_copy_used_skeletons(const void* src_dev, void* dst, int n_slices, uint64_t capacity, void* stream) {
+    if (!src_dev || !dst || n_slices < 1 || capacity < 64 || (capacity & 15) || ((uintptr_t)src_dev & 15) || ((uintptr_t)dst & 15)) {
+        pd_set_global_error("pd_copy_used_skeletons: %d slices of %llu bytes (a multiple of 16, at least 64) at 16-byte aligned addresses",
+                            n_slices, (unsigned long long)capacity);
+        return PD_E_INVALID;
+    }
+    hipLaunchKernelGGL(k_copy_used, dim3((unsigned)n_slices), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_dev,
+                       (unsigned char*)dst, (unsigned long long)capacity);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pd_set_global_error("pd_copy_used_skeletons: launch failed: %s", hipGetErrorString(e));
+        return PD_E_HIP;
+    }
+    return PD_OK;
+}

@@ -776,6 +776,51 @@ def test_skeleton_only_decode_checks_the_capacity_as_it_writes(pdec):
     eng.close()
 
 
+def test_copy_of_the_used_part_of_gathered_slices(pdec):
+    """pd_copy_used_skeletons: of every fixed-size slice the header, count tables and payload in use reach the
+    (pinned) destination, nothing behind them is touched; a slice whose buffer was too small brings its tables, a
+    slice no decode has written its header alone."""
+    import torch
+    from poseestimation_amd import _ffi, sharding, synth
+    H = W = 184
+    cap = 1 << 16
+    heat, paf = synth.batch(4, H, W, (1, 4), seed0=270, paf_order='xy')
+    dh, dp = torch.from_numpy(heat).cuda(), torch.from_numpy(paf).cuda()
+    eng = pdec.DecodeEngine(max_batch=4, max_h=H, max_w=W, mode='D')
+    eng.ctx.set_host_results(False)
+    src = torch.zeros(4 * cap, dtype=torch.uint8, device='cuda')
+    off_pay = int(_ffi.res_layout(4)[4])
+    for j, c in enumerate((cap, cap, off_pay + 64)):           # slice 2: too small for its payload; slice 3: never written
+        eng.ctx.set_skeleton_buffer(src.data_ptr() + j * cap, c)
+        eng.enqueue_device(dh.data_ptr(), dp.data_ptr(), 4 if j != 1 else 2, 23, 23, (H, W))
+        eng.ctx.sync()
+    dst = torch.full((4 * cap,), 0xEE, dtype=torch.uint8).pin_memory()
+    L = _ffi.lib()
+    assert L.pd_copy_used_skeletons(src.data_ptr(), dst.data_ptr(), 4, cap, None) == 0
+    torch.cuda.synchronize()
+    a, b = src.cpu().numpy().reshape(4, cap), dst.numpy().reshape(4, cap)
+    for j in range(4):
+        head = a[j, :64].view(np.int64)
+        if j < 2:
+            used = sharding.blob_nbytes(a[j])
+            assert head[5] == 0 and used > off_pay
+        elif j == 2:
+            used = off_pay
+            assert head[5] > 0
+        else:
+            used = 64
+        used16 = (used + 15) // 16 * 16
+        assert np.array_equal(b[j, :used], a[j, :used]), j
+        assert np.all(b[j, used16:] == 0xEE), j
+    got = sharding.SkeletonGather.results(b[None, :2])
+    want = sharding.SkeletonGather.results(a[None, :2])
+    for g, w in zip(got, want):
+        for key in ('part_count', 'person_count', 'status', 'peaks', 'persons'):
+            assert np.array_equal(g[key], w[key]), key
+    assert L.pd_copy_used_skeletons(src.data_ptr(), dst.data_ptr(), 4, cap + 8, None) == _ffi.PD_E_INVALID
+    eng.close()
+
+
 def test_submit_launches_from_the_context_thread(pdec):
     """pd_submit / pd_flush: decodes queued for the context's launcher thread write the same
     skeleton buffers as direct calls, in order, and errors surface at the flush."""
@@ -803,12 +848,14 @@ def test_submit_launches_from_the_context_thread(pdec):
     eng.close()
 
 
-def test_rounds_without_a_process_group(pdec):
+@pytest.mark.parametrize('plain_copy', ['1', '0'])
+def test_rounds_without_a_process_group(pdec, plain_copy, monkeypatch):
     """SkeletonGather(local=True): the round pipeline of a multi-GPU job in one process, the
     gather replaced by the copy to pinned memory; two contexts, two decodes each per round,
     skeleton-only contexts.  Every decode of every round arrives, in slice order."""
     import torch
     from poseestimation_amd import sharding, synth
+    monkeypatch.setenv('PD_GATHER_PLAIN_COPY', plain_copy)      # the copy engines, or the kernel that copies what is in use
     H = W = 184
     batches = [synth.batch(3, H, W, (1, 3), seed0=s, paf_order='xy') for s in (100, 110, 120)]
     want = [pdec.DecodeEngine(3, H, W, mode='D').decode_batch(h, p).packed for h, p in batches]
