@@ -790,31 +790,35 @@ def run_single(env):
             out['parity_checked_images'] = ncpu
             out['parity_ok'] = bool(ok)
         if use_dist and not args.no_cpu and gather is not None and n_scenes == B:
-            # N > 1: images of every rank, as they arrived on rank 0 through the gather, against the oracle on that
-            # rank's inputs (rendered again here from their seeds); peaks and person rows are what the gather carries
-            from oracle import decode_ref as ref
-            r_all = Results(res0, eng.mode)
-            ok, checked = True, 0
-            for rk in range(world):
-                for b in sorted({0, B - 1}):
-                    src = (b + buf0) % B
-                    hm, pm = synth.batch(1, H, W, people, seed0=rk * B + src, paf_order='xy' if args.mode == 'D' else 'yx')
-                    hf = ref.resize_cubic(hm[0], fx=8, fy=8).astype(np.float64)
-                    pf = ref.resize_cubic(pm[0], fx=8, fy=8).astype(np.float64)
-                    peaks = ref.get_peaks(hf, 0.1, args.mode, use_scipy=True)
-                    conns, special = ref.get_connections(peaks, pf, 0.05, args.mode)
-                    subset = ref.multi_person_parse(peaks, conns, special, args.mode)
-                    g = r_all.subset(rk * B + b)
-                    gp = r_all.all_peaks(rk * B + b)
-                    ok = ok and g.shape == subset.shape and np.array_equal(g[:, :18], subset[:, :18]) \
-                        and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0) \
-                        and [len(x) for x in gp] == [len(x) for x in peaks] \
-                        and all(int(a[0]) == int(c[0]) and int(a[1]) == int(c[1]) and float(a[2]) == float(c[2])
-                                for x, y in zip(gp, peaks) for a, c in zip(x, y))
-                    checked += 1
-            out['parity_checked_images'] = checked
-            out['parity_ok'] = bool(ok)
-            out['parity_note'] = 'two images of every rank from the last gathered round, as rank 0 received them'
+            try:
+                # N > 1: images of every rank, as they arrived on rank 0 through the gather, against the oracle on that
+                # rank's inputs (rendered again here from their seeds); peaks and person rows are what the gather carries
+                from oracle import decode_ref as ref
+                r_all = Results(res0, eng.mode)
+                ok, checked = True, 0
+                for rk in range(world):
+                    for b in sorted({0, B - 1}):
+                        src = (b + buf0) % B
+                        hm, pm = synth.batch(1, H, W, people, seed0=rk * B + src, paf_order='xy' if args.mode == 'D' else 'yx')
+                        hf = ref.resize_cubic(hm[0], fx=8, fy=8).astype(np.float64)
+                        pf = ref.resize_cubic(pm[0], fx=8, fy=8).astype(np.float64)
+                        peaks = ref.get_peaks(hf, 0.1, args.mode, use_scipy=True)
+                        conns, special = ref.get_connections(peaks, pf, 0.05, args.mode)
+                        subset = ref.multi_person_parse(peaks, conns, special, args.mode)
+                        g = r_all.subset(rk * B + b)
+                        gp = r_all.all_peaks(rk * B + b)
+                        ok = ok and g.shape == subset.shape and np.array_equal(g[:, :18], subset[:, :18]) \
+                            and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0) \
+                            and [len(x) for x in gp] == [len(x) for x in peaks] \
+                            and all(int(a[0]) == int(c[0]) and int(a[1]) == int(c[1]) and float(a[2]) == float(c[2])
+                                    for x, y in zip(gp, peaks) for a, c in zip(x, y))
+                        checked += 1
+                out['parity_checked_images'] = checked
+                out['parity_ok'] = bool(ok)
+                out['parity_note'] = 'two images of every rank from the last gathered round, as rank 0 received them'
+            except Exception as exc:      # a check that cannot run must not take the measured line with it
+                out['parity_ok'] = None
+                out['parity_error'] = repr(exc)
     for e in engs:
         e.close()
     return out
@@ -1045,26 +1049,30 @@ def run_multiscale(env):
             out['parity_checked_images'] = ncpu
             out['parity_ok'] = bool(ok)
         if env['use_dist'] and not args.no_cpu:
-            # N > 1: one image of every rank, as it arrived on rank 0 through the gather, against the oracle on that
-            # rank's inputs (rendered again here from their seeds)
-            from oracle import decode_ref as ref
-            r = Results(last, engs[0].mode)
-            ok = True
-            for rk in range(world):
-                rrng = np.random.RandomState(100003 + rk)
-                cnt = [int(rrng.randint(people[0], people[1] + 1)) for _ in range(NSCENE)]
-                b = (rk * 5) % NSCENE
-                outs = [synth.scene(H, W, cnt[b], 7000 + rk * NSCENE + b, paf_order='xy' if args.mode == 'D' else 'yx', scale=sc)
-                        for sc in SCALES]
-                want_h, want_p = ref.upsample_average([o[0] for o in outs], [o[1] for o in outs], [(0, 0)] * 4, (H, W))
-                cand, peaks, subset = ref.decode(want_h, want_p, 0.1, 0.05, args.mode)
-                g = r.subset(rk * B + b)
-                ok = ok and g.shape == subset.shape and np.array_equal(g[:, :18], subset[:, :18]) \
-                    and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0) \
-                    and np.array_equal(r.candidate(rk * B + b)[:, :2], cand[:, :2])
-            out['parity_checked_images'] = world
-            out['parity_ok'] = bool(ok)
-            out['parity_note'] = 'one image of every rank from the last gathered step, as rank 0 received it'
+            try:
+                # N > 1: one image of every rank, as it arrived on rank 0 through the gather, against the oracle on that
+                # rank's inputs (rendered again here from their seeds)
+                from oracle import decode_ref as ref
+                r = Results(last, engs[0].mode)
+                ok = True
+                for rk in range(world):
+                    rrng = np.random.RandomState(100003 + rk)
+                    cnt = [int(rrng.randint(people[0], people[1] + 1)) for _ in range(NSCENE)]
+                    b = (rk * 5) % NSCENE
+                    outs = [synth.scene(H, W, cnt[b], 7000 + rk * NSCENE + b, paf_order='xy' if args.mode == 'D' else 'yx', scale=sc)
+                            for sc in SCALES]
+                    want_h, want_p = ref.upsample_average([o[0] for o in outs], [o[1] for o in outs], [(0, 0)] * 4, (H, W))
+                    cand, peaks, subset = ref.decode(want_h, want_p, 0.1, 0.05, args.mode)
+                    g = r.subset(rk * B + b)
+                    ok = ok and g.shape == subset.shape and np.array_equal(g[:, :18], subset[:, :18]) \
+                        and np.allclose(g[:, 18:], subset[:, 18:], rtol=1e-5, atol=0) \
+                        and np.array_equal(r.candidate(rk * B + b)[:, :2], cand[:, :2])
+                out['parity_checked_images'] = world
+                out['parity_ok'] = bool(ok)
+                out['parity_note'] = 'one image of every rank from the last gathered step, as rank 0 received it'
+            except Exception as exc:
+                out['parity_ok'] = None
+                out['parity_error'] = repr(exc)
     for e in engs:
         e.close()
     return out
