@@ -210,6 +210,7 @@ def main():
     ap.add_argument('--multiscale', action='store_true')
     ap.add_argument('--images', action='store_true', help='the image resize + pad in front of the network instead of the decode')
     ap.add_argument('--shapes', action='store_true', help='maps of one to three pixels a side and long strips')
+    ap.add_argument('--impl', type=int, default=0, help='peak-stage implementation (pd_set_impl): 0 candidate filter, 1 per pixel, 2 exact streaming')
     ap.add_argument('--large', action='store_true', help='maps of 60..91 x 70..91 network pixels')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
@@ -233,6 +234,7 @@ def main():
         want = [oracle(hm, pm, H, W, mode, t1, t2) for hm, pm in imgs]
         eng = pdec.DecodeEngine(max_batch=len(imgs), max_h=8 * heat0.shape[0], max_w=8 * heat0.shape[1], mode=mode,
                                 max_peaks_per_part=512 if args.large else 256, max_persons=960 if args.large else 204, max_pairs_per_image=2000000 if args.large else 400000)
+        eng.ctx.set_impl(args.impl)
         tag = 'case %d (seed %d) mode %s %dx%d -> %dx%d thr %.2f/%.2f' % (case, args.seed, mode, heat0.shape[0], heat0.shape[1],
                                                                          H, W, t1, t2)
         expect_index = [b for b, wv in enumerate(want) if wv[3] is IndexError]
