@@ -450,6 +450,7 @@ struct CellFilterArgs {
     int32_t* cand_count;   // [B][18] candidates seen per plane (may exceed CK)
     int32_t* cand_n;       // [KF_NSEG] entries asked for per segment (may exceed cand_seg_cap)
     int CK;
+    int seg_by_xcd;        // k_cells_filter: the candidates of a plane go to one of the four segments of the XCD that staged it
 };
 
 
@@ -827,9 +828,9 @@ k_cells_filter(CellsFilterArgs args) {
     unsigned short* list = (unsigned short*)(lds + h * w);
     if (tid == 0) sh.n_cand = 0;
     // ---- the plane to LDS, its maximum, its planar copy
-    float* copy = a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w;
+    float* copy = a.planar_out ? a.planar_out + ((size_t)b * PD_CH_HEAT + part) * h * w : nullptr;
     float m = 0.f;
-    if (a.nhwc) {  // from the network's interleaved output, leaving the planar copy behind
+    if (a.nhwc) {  // from the network's interleaved output (leaving a planar copy behind if one is asked for)
         const float* pix = a.nhwc + (size_t)b * h * w * PD_CH_HEAT + part;
         for (int i0 = 0; i0 < h * w; i0 += 256 * 9) {
             float t[9];
@@ -844,7 +845,7 @@ k_cells_filter(CellsFilterArgs args) {
                 if (i < h * w) {
                     P[i] = t[k];
                     m = absmax_step(m, t[k]);
-                    copy[i] = t[k];
+                    if (copy) copy[i] = t[k];
                 }
             }
         }
@@ -967,7 +968,9 @@ k_cells_filter(CellsFilterArgs args) {
     filter_cells_lds<true>(args.f, sh, P, list, n_reg, 1, plane, thr_lo, e2, lane);
     filter_cells_lds<false>(args.f, sh, P, list + n_cells - 1, n_edge, -1, plane, thr_lo, e2, lane);
     __syncthreads();
-    const int seg = plane % KF_NSEG;
+    // which segment: spread by plane, or -- so that the verification of an image's candidates can run on the XCD whose L2
+    // holds that image's part of the network output -- one of the four segments of this workgroup's XCD
+    const int seg = args.f.seg_by_xcd ? (int)(blockIdx.x % 8) * (KF_NSEG / 8) + (plane & (KF_NSEG / 8 - 1)) : plane % KF_NSEG;
     if (tid == 64 && n_reg) atomicAdd(a.n_reg + seg, n_reg);  // the list lengths, for the statistics only
     if (tid == 128 && n_edge) atomicAdd(a.n_edge + seg, n_edge);
     const int nc = min(sh.n_cand, KF_LCAND_PLANE);
@@ -1279,6 +1282,7 @@ struct VerifyArgs {
     RawPeak* raw;
     int32_t* raw_count;
     int PK;
+    int by_xcd;  // the workgroups of XCD x (workgroup i runs on XCD i % 8) take the candidates of segments 4x .. 4x+3
 };
 
 // Exact float64 decision for every candidate.  32 lanes per candidate, VF_CAND candidates per
@@ -1311,9 +1315,17 @@ k_verify(VerifyArgs a) {
     segment_prefix(a.cand_n, a.cand_seg_cap, s_pref, tid);
     const int total = s_pref[KF_NSEG];
     const int H = a.H, W = a.W, h = a.h, w = a.w;
-    for (int base = blockIdx.x * VF_CAND; base < total; base += gridDim.x * VF_CAND) {
+    int c_lo = 0, c_hi = total, first = blockIdx.x, step = gridDim.x;
+    if (a.by_xcd) {  // (the grid is a multiple of 8)
+        const int xcd = blockIdx.x % 8;
+        c_lo = s_pref[xcd * (KF_NSEG / 8)];
+        c_hi = s_pref[(xcd + 1) * (KF_NSEG / 8)];
+        first = blockIdx.x / 8;
+        step = gridDim.x / 8;
+    }
+    for (int base = c_lo + first * VF_CAND; base < c_hi; base += step * VF_CAND) {
         const int ci = base + half;
-        bool active = ci < total;
+        bool active = ci < c_hi;
         int Y = 0, X = 0, plane = 0, plane_total = 0;
         double u13 = 0.0;
         if (active) {
@@ -1522,6 +1534,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     f.cand_count = ctx->cand_count;
     f.cand_n = counters;
     f.CK = CK;
+    f.seg_by_xcd = 0;
 
     // cand_count and the list counters were cleared together with raw_count
     static const bool split_cells = [] {
@@ -1539,7 +1552,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         const char* v = getenv("PD_TILE_FILTER");
         return !(v && *v && *v != '0');
     }();
-    bool nhwc_verify = false;
+    bool nhwc_verify = false, verify_by_xcd = false;
     if (small_map && gather && !split_cells && !plane_form && hc <= h && wc <= w && hc < 128 && wc < 128) {
         CellsFilterArgs cf;
         cf.c = c;
@@ -1559,6 +1572,16 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
         CellsFilterArgs cf;
         cf.c = c;
         cf.f = f;
+        static const bool keep_copy = [] {
+            const char* v = getenv("PD_PLANAR_COPY");
+            return v && *v && *v != '0';
+        }();  // comparison runs: the planar copy written on the way and read by the verification
+        if (gather && !keep_copy) {
+            cf.c.planar_out = nullptr;
+            cf.f.seg_by_xcd = 1;
+            nhwc_verify = true;
+            verify_by_xcd = true;
+        }
         if (!gather) {
             pd_prof_begin(ctx, PD_STAGE_PLANAR);
             hipLaunchKernelGGL(k_heat_planar, dim3((h * w + KP_PIX - 1) / KP_PIX, B), dim3(256), 0, ctx->stream, ctx->lo_heat,
@@ -1617,6 +1640,7 @@ int pd_launch_peaks_filtered(pd_ctx* ctx, double thr) {
     v.raw = ctx->raw;
     v.raw_count = ctx->raw_count;
     v.PK = ctx->cfg.max_peaks_per_part;
+    v.by_xcd = verify_by_xcd ? 1 : 0;
     int vblocks = B * 12 * (256 / VF_NT);
     if (vblocks > 1024 * (256 / VF_NT)) vblocks = 1024 * (256 / VF_NT);
     pd_prof_begin(ctx, PD_STAGE_VERIFY);
@@ -1879,6 +1903,7 @@ int pd_launch_peaks_filtered_full(pd_ctx* ctx, double thr) {
     v.raw = ctx->raw;
     v.raw_count = ctx->raw_count;
     v.PK = ctx->cfg.max_peaks_per_part;
+    v.by_xcd = 0;
     int vblocks = B * 12 * (256 / VF_NT);
     if (vblocks > 1024 * (256 / VF_NT)) vblocks = 1024 * (256 / VF_NT);
     pd_prof_begin(ctx, PD_STAGE_VERIFY);

@@ -428,7 +428,7 @@ def test_comparison_switches_leave_the_results_alone():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
-    for name in ('', 'PD_TILE_FILTER', 'PD_SPLIT_CELLS', 'PD_PLANAR_FIRST', 'PD_SEPARATE_PACK', 'PD_SEPARATE_SORT'):
+    for name in ('', 'PD_TILE_FILTER', 'PD_SPLIT_CELLS', 'PD_PLANAR_FIRST', 'PD_PLANAR_COPY', 'PD_SEPARATE_PACK', 'PD_SEPARATE_SORT'):
         env = {k: v for k, v in os.environ.items() if not k.startswith('PD_')}
         if name:
             env[name] = '1'
